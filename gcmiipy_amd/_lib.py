@@ -1,0 +1,82 @@
+"""ctypes binding of libgcmcore.so (include/gcmcore.h).
+
+The library is the product: if it is missing or exports fewer symbols than the
+header declares, importing this module raises -- there is no NumPy fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("GCMCORE_LIB", os.path.join(_HERE, "lib", "libgcmcore.so"))
+
+ABI_VERSION = 1
+
+# enums of include/gcmcore.h
+SW2D, SW2D_TEMP, PE2D, PE25D = 1, 2, 3, 4
+P, U, V, T, Q = 0, 1, 2, 3, 4
+TRACER_NONE, TRACER_UPWIND, TRACER_VANLEER = 0, 1, 2
+VARIANT_AUTO, VARIANT_STAGED, VARIANT_FUSED = 0, 1, 2
+DIAG_ANY_NAN, DIAG_MAX_U, DIAG_MEAN_P, DIAG_SUM_P, DIAG_MIN_U, DIAG_MAX_V, DIAG_MIN_V = range(7)
+OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+
+_dp = C.POINTER(C.c_double)
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("model", C.c_int32), ("width", C.c_int32),
+        ("height", C.c_int32), ("layers", C.c_int32), ("tracer", C.c_int32),
+        ("variant", C.c_int32), ("filter", C.c_int32), ("nranks", C.c_int32),
+        ("rank", C.c_int32), ("global_height", C.c_int32), ("row0", C.c_int32),
+        ("device", C.c_int32), ("reserved0", C.c_int32),
+        ("dx", C.c_double), ("dy", C.c_double), ("ptop", C.c_double),
+        ("dx_j", _dp), ("dx_h", _dp), ("sig", _dp), ("dsig", _dp), ("sigb", _dp),
+        ("sigt", _dp), ("heightmap", _dp), ("stream", C.c_void_p),
+    ]
+
+
+_H = C.c_void_p
+# name -> (restype, argtypes); every symbol include/gcmcore.h declares
+SYMBOLS = {
+    "gcm_abi_version": (C.c_int, []),
+    "gcm_device_count": (C.c_int, []),
+    "gcm_build_info": (C.c_char_p, []),
+    "gcm_create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
+    "gcm_destroy": (C.c_int, [_H]),
+    "gcm_last_error": (C.c_char_p, [_H]),
+    "gcm_set_state": (C.c_int, [_H] + [C.c_void_p] * 5),
+    "gcm_get_state": (C.c_int, [_H] + [C.c_void_p] * 5),
+    "gcm_step": (C.c_int, [_H, C.c_int, C.c_double]),
+    "gcm_half_step": (C.c_int, [_H, C.c_int, C.c_double]),
+    "gcm_get_star": (C.c_int, [_H] + [C.c_void_p] * 5),
+    "gcm_set_star": (C.c_int, [_H] + [C.c_void_p] * 5),
+    "gcm_diag": (C.c_int, [_H, C.c_int, _dp]),
+    "gcm_halo_bytes": (C.c_size_t, [_H]),
+    "gcm_halo_pack": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
+    "gcm_halo_unpack": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
+    "gcm_step_interior": (C.c_int, [_H, C.c_double, C.c_void_p]),
+    "gcm_step_boundary": (C.c_int, [_H, C.c_double, C.c_void_p]),
+    "gcm_sync": (C.c_int, [_H]),
+    "gcm_time_steps": (C.c_int, [_H, C.c_int, C.c_double, _dp, _dp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "gcmiipy_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C gcmiipy_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise ImportError("gcmiipy_amd: %s does not export %s" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gcm_abi_version() != ABI_VERSION:
+        raise ImportError("gcmiipy_amd: ABI version mismatch")
+    return lib
+
+
+lib = _load()

@@ -1,0 +1,178 @@
+"""`Core`: one resident model state on one MI355X behind the C ABI.
+
+This is the fast path: state stays in HBM, `step(n)` launches n fused Matsuno
+steps, `get_state()` copies back once.  The reference-shaped drop-in functions
+(matsuno_c_grid.py, matsumo_temp.py, dynamics.py ... in this package) are thin
+wrappers that move arrays through a cached Core per call.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib
+
+
+class GcmError(RuntimeError):
+    pass
+
+
+def _check(rc, h=None):
+    if rc == _lib.OK:
+        return
+    msg = lib.gcm_last_error(h).decode() if (h or rc) else ""
+    if rc == _lib.ERR_ARG:
+        raise ValueError(msg or "gcmcore: bad argument")
+    raise GcmError("gcmcore error %d: %s" % (rc, msg))
+
+
+def as_f64(x, shape=None, name="array"):
+    """float64 C-contiguous ndarray of `shape`; mirrors the reference's shape asserts
+    (temperature.py:9,17; dynamics.py:203) with ValueError."""
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, a.shape, tuple(shape)))
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _tab(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Core:
+    """Owns a gcm_handle.  Field order of set/get is (p, u, v, t, q)."""
+
+    def __init__(self, model, width, height, layers=1, dx=0.0, tracer=_lib.TRACER_NONE,
+                 variant=_lib.VARIANT_AUTO, geom=None, filter=True, nranks=1, rank=0,
+                 global_height=None, row0=0, device=-1, stream=None):
+        self.model, self.W, self.H, self.L = model, int(width), int(height), int(layers)
+        self.nranks, self.rank = nranks, rank
+        cfg = _lib.Config()
+        cfg.abi_version = _lib.ABI_VERSION
+        cfg.model = model
+        cfg.width, cfg.height, cfg.layers = self.W, self.H, self.L
+        cfg.tracer, cfg.variant, cfg.filter = tracer, variant, 1 if filter else 0
+        cfg.nranks, cfg.rank = nranks, rank
+        cfg.global_height = self.H if global_height is None else int(global_height)
+        cfg.row0 = row0
+        cfg.device = device
+        cfg.dx = float(dx)
+        cfg.stream = stream
+        self._keep = []
+        if model == _lib.PE25D:
+            if geom is None:
+                raise ValueError("GCM_PE25D needs a geometry (gcmiipy_amd.geometry.gen_geometry)")
+            gh = cfg.global_height
+
+            def tab(x, n):
+                a = as_f64(np.asarray(x, dtype=np.float64).reshape(-1), (n,), "geometry table")
+                self._keep.append(a)
+                return _tab(a)
+
+            cfg.dy = float(geom.dy)
+            cfg.ptop = float(geom.ptop)
+            cfg.dx_j, cfg.dx_h = tab(geom.dx_j, gh), tab(geom.dx_h, gh)
+            cfg.sig, cfg.dsig = tab(geom.sig, self.L), tab(geom.dsig, self.L)
+            cfg.sigb, cfg.sigt = tab(geom.sigb, self.L), tab(geom.sigt, self.L)
+            hm = np.asarray(geom.heightmap, dtype=np.float64)
+            if hm.shape == (gh, self.W):
+                hm = hm[row0:row0 + self.H]
+            cfg.heightmap = tab(hm, self.H * self.W)
+        self._h = _lib._H()
+        rc = lib.gcm_create(C.byref(cfg), C.byref(self._h))
+        if rc != _lib.OK:
+            msg = lib.gcm_last_error(None).decode()
+            self._h = None
+            if rc == _lib.ERR_ARG:
+                raise ValueError(msg)
+            raise GcmError("gcm_create failed (%d): %s" % (rc, msg))
+        self.is3d = model == _lib.PE25D
+
+    # -- shapes ----------------------------------------------------------------
+    def shape_of(self, field):
+        if self.is3d and field != _lib.P:
+            return (self.L, self.H, self.W)
+        return (self.H, self.W)
+
+    def _prep_in(self, arrs):
+        out = []
+        for f, a in enumerate(arrs):
+            out.append(None if a is None else as_f64(a, self.shape_of(f), "pu vtq"[f] if f < 2 else "puvtq"[f]))
+        return out
+
+    # -- state -------------------------------------------------------------------
+    def set_state(self, p=None, u=None, v=None, t=None, q=None):
+        a = self._prep_in((p, u, v, t, q))
+        _check(lib.gcm_set_state(self._h, *[_ptr(x) for x in a]), self._h)
+
+    def set_star(self, p=None, u=None, v=None, t=None, q=None):
+        a = self._prep_in((p, u, v, t, q))
+        _check(lib.gcm_set_star(self._h, *[_ptr(x) for x in a]), self._h)
+
+    def _get(self, fn, fields):
+        out = [np.empty(self.shape_of(f)) if f in fields else None for f in range(5)]
+        _check(fn(self._h, *[_ptr(x) for x in out]), self._h)
+        return out
+
+    def get_state(self, fields=(_lib.P, _lib.U, _lib.V, _lib.T, _lib.Q)):
+        """-> [p, u, v, t, q] (None for fields not requested)"""
+        return self._get(lib.gcm_get_state, fields)
+
+    def get_star(self, fields=(_lib.P, _lib.U, _lib.V, _lib.T)):
+        return self._get(lib.gcm_get_star, fields)
+
+    # -- stepping ------------------------------------------------------------------
+    def step(self, nsteps, dt):
+        _check(lib.gcm_step(self._h, int(nsteps), float(dt)), self._h)
+
+    def half_step(self, stage, dt):
+        _check(lib.gcm_half_step(self._h, int(stage), float(dt)), self._h)
+
+    def sync(self):
+        _check(lib.gcm_sync(self._h), self._h)
+
+    def diag(self, kind):
+        out = C.c_double()
+        _check(lib.gcm_diag(self._h, kind, C.byref(out)), self._h)
+        return out.value
+
+    def time_steps(self, nsteps, dt, per_kernel=True):
+        ms, kms = C.c_double(), C.c_double()
+        _check(lib.gcm_time_steps(self._h, int(nsteps), float(dt), C.byref(ms),
+                                  C.byref(kms) if per_kernel else None), self._h)
+        return ms.value, (kms.value if per_kernel else None)
+
+    # -- latitude-band plumbing ------------------------------------------------------
+    def halo_bytes(self):
+        return lib.gcm_halo_bytes(self._h)
+
+    def halo_pack(self, side, dev_ptr, stream=None):
+        _check(lib.gcm_halo_pack(self._h, side, dev_ptr, stream), self._h)
+
+    def halo_unpack(self, side, dev_ptr, stream=None):
+        _check(lib.gcm_halo_unpack(self._h, side, dev_ptr, stream), self._h)
+
+    def step_interior(self, dt, stream=None):
+        _check(lib.gcm_step_interior(self._h, float(dt), stream), self._h)
+
+    def step_boundary(self, dt, stream=None):
+        _check(lib.gcm_step_boundary(self._h, float(dt), stream), self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.gcm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_count():
+    return lib.gcm_device_count()

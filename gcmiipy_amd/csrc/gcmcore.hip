@@ -1,0 +1,579 @@
+// Host side of libgcmcore.so: the C ABI of include/gcmcore.h.
+// Owns device buffers, picks kernels, launches on the handle's stream.  There is
+// no CPU fallback anywhere in this file: without a HIP device gcm_create fails.
+#include "../../include/gcmcore.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pe25d_kernels.h"
+#include "sw2d_kernels.h"
+
+using namespace gcm;
+
+namespace {
+thread_local std::string g_create_error;
+}
+
+struct gcm_handle {
+    gcm_config cfg{};
+    int W = 0, H = 0, L = 1;
+    bool wrap = true;  // nranks == 1: periodic rows by index arithmetic
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<void *> allocs;
+
+    // 2-D models: per-field arrays of (H + 2*kGhost) rows; pointers address interior row 0
+    double *cur[GCM_NFIELDS] = {}, *nxt[GCM_NFIELDS] = {}, *star[GCM_NFIELDS] = {};
+    double *geo = nullptr, *irho = nullptr, *sst = nullptr, *qtmp = nullptr;
+    bool has[GCM_NFIELDS] = {};
+    bool star_valid = false;
+    int variant = GCM_VARIANT_FUSED;
+    int rows_per_band = 32;
+
+    // diagnostics scratch
+    double *diag_dev = nullptr;
+    static constexpr int kDiagBlocks = 512;
+
+    // per-launch timing of the dominant kernel (gcm_time_steps second pass)
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+
+    Pe25d *pe = nullptr;  // GCM_PE25D state (pe25d_kernels.h)
+};
+
+#define HIPCHK(h, call)                                                                    \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            char b_[512];                                                                  \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                  \
+            (h)->err = b_;                                                                 \
+            return GCM_ERR_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+static int fail(gcm_handle *h, int code, const std::string &msg) {
+    if (h) h->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+static int alloc_field(gcm_handle *h, double **p) {
+    const size_t n = (size_t)(h->H + 2 * kGhost) * h->W;
+    void *d = nullptr;
+    HIPCHK(h, hipMalloc(&d, n * sizeof(double)));
+    HIPCHK(h, hipMemsetAsync(d, 0, n * sizeof(double), h->stream));
+    h->allocs.push_back(d);
+    *p = (double *)d + (size_t)kGhost * h->W;
+    return GCM_OK;
+}
+
+extern "C" {
+
+int gcm_abi_version(void) { return GCM_ABI_VERSION; }
+
+int gcm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *gcm_build_info(void) {
+    return "libgcmcore gfx950 (hipcc " __VERSION__ "), fp64, kernels: sw2d staged+fused, pe25d";
+}
+
+const char *gcm_last_error(const gcm_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int gcm_destroy(gcm_handle *h) {
+    if (!h) return GCM_OK;
+    if (h->cfg.device >= 0) (void)hipSetDevice(h->cfg.device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->pe) pe25d_destroy(h->pe);
+    for (void *p : h->allocs) (void)hipFree(p);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    delete h;
+    return GCM_OK;
+}
+
+int gcm_create(const gcm_config *cfg, gcm_handle **out) {
+    if (!cfg || !out) return fail(nullptr, GCM_ERR_ARG, "gcm_create: null argument");
+    *out = nullptr;
+    if (cfg->abi_version != GCM_ABI_VERSION)
+        return fail(nullptr, GCM_ERR_ARG, "gcm_create: abi_version mismatch");
+    if (cfg->width < 1 || cfg->height < 1 || cfg->layers < 1)
+        return fail(nullptr, GCM_ERR_ARG, "gcm_create: width/height/layers must be >= 1");
+    if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks)
+        return fail(nullptr, GCM_ERR_ARG, "gcm_create: bad rank/nranks");
+    if (cfg->nranks > 1 && cfg->height < kGhost)
+        return fail(nullptr, GCM_ERR_ARG, "gcm_create: a latitude band needs >= 2 rows");
+    if (gcm_device_count() < 1)
+        return fail(nullptr, GCM_ERR_NODEVICE,
+                    "gcm_create: no HIP device visible; libgcmcore has no CPU fallback");
+    gcm_handle *h = new gcm_handle;
+    h->cfg = *cfg;
+    h->W = cfg->width;
+    h->H = cfg->height;
+    h->L = cfg->layers;
+    h->wrap = cfg->nranks == 1;
+    h->stream = (hipStream_t)cfg->stream;
+    int rc = GCM_OK;
+    auto bail = [&](int code, const std::string &m) {
+        g_create_error = m.empty() ? h->err : m;
+        gcm_destroy(h);
+        return code;
+    };
+    if (cfg->device >= 0 && hipSetDevice(cfg->device) != hipSuccess)
+        return bail(GCM_ERR_HIP, "gcm_create: hipSetDevice failed");
+
+    switch (cfg->model) {
+        case GCM_SW2D:
+        case GCM_SW2D_TEMP: {
+            if (!(cfg->dx > 0)) return bail(GCM_ERR_ARG, "gcm_create: dx must be > 0");
+            const bool temp = cfg->model == GCM_SW2D_TEMP;
+            if (!temp && cfg->tracer != GCM_TRACER_NONE)
+                return bail(GCM_ERR_ARG, "gcm_create: tracer needs GCM_SW2D_TEMP");
+            if (cfg->tracer < 0 || cfg->tracer > GCM_TRACER_VANLEER)
+                return bail(GCM_ERR_ARG, "gcm_create: bad tracer");
+            h->has[GCM_U] = h->has[GCM_V] = h->has[GCM_P] = true;
+            h->has[GCM_T] = temp;
+            h->has[GCM_Q] = temp && cfg->tracer != GCM_TRACER_NONE;
+            h->variant = cfg->variant == GCM_VARIANT_AUTO ? GCM_VARIANT_FUSED : cfg->variant;
+            if (h->variant != GCM_VARIANT_FUSED && h->variant != GCM_VARIANT_STAGED)
+                return bail(GCM_ERR_ARG, "gcm_create: bad variant");
+            for (int f = 0; f < GCM_NFIELDS; ++f) {
+                if (!h->has[f]) continue;
+                if ((rc = alloc_field(h, &h->cur[f]))) return bail(rc, "");
+                if ((rc = alloc_field(h, &h->nxt[f]))) return bail(rc, "");
+                if (f != GCM_Q && (rc = alloc_field(h, &h->star[f]))) return bail(rc, "");
+            }
+            if (temp) {
+                if ((rc = alloc_field(h, &h->geo))) return bail(rc, "");
+                if ((rc = alloc_field(h, &h->irho))) return bail(rc, "");
+                if ((rc = alloc_field(h, &h->sst))) return bail(rc, "");
+            }
+            if (h->has[GCM_Q] && (rc = alloc_field(h, &h->qtmp))) return bail(rc, "");
+            h->rows_per_band = sw2d_fused_rows_per_band(h->W, h->H);
+            break;
+        }
+        case GCM_PE25D: {
+            std::string msg;
+            h->pe = pe25d_create(*cfg, h->stream, &msg);
+            if (!h->pe) return bail(msg.find("hip") == 0 ? GCM_ERR_HIP : GCM_ERR_ARG, msg);
+            h->has[GCM_P] = h->has[GCM_U] = h->has[GCM_V] = h->has[GCM_T] = h->has[GCM_Q] = true;
+            break;
+        }
+        default:
+            return bail(GCM_ERR_UNSUPPORTED, "gcm_create: model not built in this round");
+    }
+    void *d = nullptr;
+    if (hipMalloc(&d, sizeof(double) * 4 * gcm_handle::kDiagBlocks) != hipSuccess)
+        return bail(GCM_ERR_HIP, "gcm_create: hipMalloc(diag) failed");
+    h->allocs.push_back(d);
+    h->diag_dev = (double *)d;
+    if (hipStreamSynchronize(h->stream) != hipSuccess)
+        return bail(GCM_ERR_HIP, "gcm_create: stream sync failed");
+    *out = h;
+    return GCM_OK;
+}
+
+// ------------------------------------------------------------------ state transfer
+static int xfer(gcm_handle *h, double *const dev[GCM_NFIELDS], const double *const hostc[GCM_NFIELDS],
+                double *const hostm[GCM_NFIELDS], bool to_device) {
+    const size_t bytes = (size_t)h->H * h->W * sizeof(double);
+    for (int f = 0; f < GCM_NFIELDS; ++f) {
+        const void *src = hostc ? (const void *)hostc[f] : (const void *)hostm[f];
+        if (!src) continue;
+        if (!h->has[f] || !dev[f])
+            return fail(h, GCM_ERR_ARG, "state transfer: field not part of this model");
+        if (to_device)
+            HIPCHK(h, hipMemcpyAsync(dev[f], hostc[f], bytes, hipMemcpyHostToDevice, h->stream));
+        else
+            HIPCHK(h, hipMemcpyAsync(hostm[f], dev[f], bytes, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return GCM_OK;
+}
+
+int gcm_set_state(gcm_handle *h, const double *p, const double *u, const double *v,
+                  const double *t, const double *q) {
+    if (!h) return GCM_ERR_ARG;
+    if (h->pe) return pe25d_set(h->pe, false, p, u, v, t, q, &h->err);
+    const double *src[GCM_NFIELDS] = {p, u, v, t, q};
+    h->star_valid = false;
+    return xfer(h, h->cur, src, nullptr, true);
+}
+
+int gcm_get_state(gcm_handle *h, double *p, double *u, double *v, double *t, double *q) {
+    if (!h) return GCM_ERR_ARG;
+    if (h->pe) return pe25d_get(h->pe, false, p, u, v, t, q, &h->err);
+    double *dst[GCM_NFIELDS] = {p, u, v, t, q};
+    return xfer(h, h->cur, nullptr, dst, false);
+}
+
+int gcm_set_star(gcm_handle *h, const double *p, const double *u, const double *v,
+                 const double *t, const double *q) {
+    if (!h) return GCM_ERR_ARG;
+    if (h->pe) return pe25d_set(h->pe, true, p, u, v, t, q, &h->err);
+    if (q) return fail(h, GCM_ERR_ARG, "set_star: the tracer has no predicted state");
+    const double *src[GCM_NFIELDS] = {p, u, v, t, nullptr};
+    int rc = xfer(h, h->star, src, nullptr, true);
+    if (rc == GCM_OK) h->star_valid = true;
+    return rc;
+}
+
+int gcm_get_star(gcm_handle *h, double *p, double *u, double *v, double *t, double *q) {
+    if (!h) return GCM_ERR_ARG;
+    if (h->pe) return pe25d_get(h->pe, true, p, u, v, t, q, &h->err);
+    if (!h->star_valid) return fail(h, GCM_ERR_STATE, "get_star: no predicted state yet");
+    if (q) return fail(h, GCM_ERR_ARG, "get_star: the tracer has no predicted state");
+    double *dst[GCM_NFIELDS] = {p, u, v, t, nullptr};
+    return xfer(h, h->star, nullptr, dst, false);
+}
+
+// ------------------------------------------------------------------ stepping (2-D)
+static Sw2dArgs base_args(gcm_handle *h, double dt) {
+    Sw2dArgs a{};
+    a.bu = h->cur[GCM_U];
+    a.bv = h->cur[GCM_V];
+    a.bp = h->cur[GCM_P];
+    a.bt = h->cur[GCM_T];
+    a.bq = h->cur[GCM_Q];
+    a.W = h->W;
+    a.H = h->H;
+    a.wrap_j = h->wrap ? 1 : 0;
+    a.j0 = 0;
+    a.j1 = h->H;
+    a.rows_per_band = h->rows_per_band;
+    a.dt = dt;
+    a.dx = h->cfg.dx;
+    a.inv_dx = 1.0 / h->cfg.dx;
+    a.dx2 = h->cfg.dx * h->cfg.dx;
+    a.inv_dx2 = 1.0 / (h->cfg.dx * h->cfg.dx);
+    return a;
+}
+
+static void swap_state(gcm_handle *h) {
+    for (int f = 0; f < GCM_NFIELDS; ++f) std::swap(h->cur[f], h->nxt[f]);
+}
+
+static void tick(gcm_handle *h, hipStream_t s) {
+    if (h->timing && h->ev_used < h->ev.size()) (void)hipEventRecord(h->ev[h->ev_used++], s);
+}
+
+// predictor (stage 0) or corrector (stage 1) of the staged variant over rows [j0, j1)
+static void staged_stage(gcm_handle *h, int stage, double dt, int j0, int j1, hipStream_t s) {
+    const bool temp = h->cfg.model == GCM_SW2D_TEMP;
+    double *const *S = stage == 0 ? h->cur : h->star;
+    double *const *O = stage == 0 ? h->star : h->nxt;
+    Sw2dArgs a = base_args(h, dt);
+    a.su = S[GCM_U];
+    a.sv = S[GCM_V];
+    a.sp = S[GCM_P];
+    a.st = S[GCM_T];
+    a.ou = O[GCM_U];
+    a.ov = O[GCM_V];
+    a.op = O[GCM_P];
+    a.ot = O[GCM_T];
+    a.j0 = j0;
+    a.j1 = j1;
+    if (temp) {
+        Sw2dArgs d = a;
+        d.dgeo = h->geo;
+        d.dirho = h->irho;
+        d.dst = h->sst;
+        if (!h->wrap) {  // stencil reaches one row beyond the rows produced
+            d.j0 = j0 - 1;
+            d.j1 = j1 + 1;
+        }
+        launch_sw2d_derive(d, s);
+        a.sgeo = h->geo;
+        a.sirho = h->irho;
+        a.sst = h->sst;
+    }
+    launch_sw2d_stage(a, temp, s);
+}
+
+static void staged_tracer(gcm_handle *h, double dt, int j0, int j1, hipStream_t s) {
+    if (!h->has[GCM_Q]) return;
+    const bool lim = h->cfg.tracer == GCM_TRACER_VANLEER;
+    Sw2dArgs a = base_args(h, dt);
+    a.j0 = j0;
+    a.j1 = j1;
+    launch_tracer_axis(a, 0, lim, h->cur[GCM_Q], h->qtmp, s);
+    launch_tracer_axis(a, 1, lim, h->qtmp, h->nxt[GCM_Q], s);
+}
+
+// one full Matsuno step producing rows [j0, j1) of nxt from cur (ghost rows already valid)
+static void step_rows(gcm_handle *h, double dt, int j0, int j1, hipStream_t s) {
+    if (j1 <= j0) return;
+    const bool temp = h->cfg.model == GCM_SW2D_TEMP;
+    if (h->variant == GCM_VARIANT_FUSED) {
+        Sw2dArgs a = base_args(h, dt);
+        a.ou = h->nxt[GCM_U];
+        a.ov = h->nxt[GCM_V];
+        a.op = h->nxt[GCM_P];
+        a.ot = h->nxt[GCM_T];
+        a.oq = h->nxt[GCM_Q];
+        a.j0 = j0;
+        a.j1 = j1;
+        tick(h, s);
+        launch_sw2d_fused(a, temp, h->has[GCM_Q] ? h->cfg.tracer : 0, s);
+        tick(h, s);
+    } else {
+        // the predicted state is needed one row beyond the rows produced
+        const int e = h->wrap ? 0 : 1;
+        staged_stage(h, 0, dt, j0 - e, j1 + e, s);
+        tick(h, s);
+        staged_stage(h, 1, dt, j0, j1, s);
+        tick(h, s);
+        staged_tracer(h, dt, j0, j1, s);
+    }
+}
+
+int gcm_step(gcm_handle *h, int nsteps, double dt) {
+    if (!h || nsteps < 0) return GCM_ERR_ARG;
+    if (h->cfg.device >= 0) HIPCHK(h, hipSetDevice(h->cfg.device));
+    if (h->pe) {
+        for (int n = 0; n < nsteps; ++n) {
+            int rc = pe25d_step(h->pe, dt, h->stream, &h->err);
+            if (rc) return rc;
+        }
+        return GCM_OK;
+    }
+    if (!h->wrap && nsteps > 1)
+        return fail(h, GCM_ERR_STATE,
+                    "gcm_step: a latitude band needs a ghost-row exchange between steps");
+    for (int n = 0; n < nsteps; ++n) {
+        step_rows(h, dt, 0, h->H, h->stream);
+        swap_state(h);
+    }
+    h->star_valid = false;
+    HIPCHK(h, hipGetLastError());
+    return GCM_OK;
+}
+
+int gcm_step_interior(gcm_handle *h, double dt, void *stream) {
+    if (!h) return GCM_ERR_ARG;
+    if (h->pe) return pe25d_step_part(h->pe, 0, dt, (hipStream_t)stream, &h->err);
+    if (h->wrap) return fail(h, GCM_ERR_STATE, "step_interior: handle is not a latitude band");
+    step_rows(h, dt, kGhost, h->H - kGhost, (hipStream_t)stream);
+    HIPCHK(h, hipGetLastError());
+    return GCM_OK;
+}
+
+int gcm_step_boundary(gcm_handle *h, double dt, void *stream) {
+    if (!h) return GCM_ERR_ARG;
+    if (h->pe) return pe25d_step_part(h->pe, 1, dt, (hipStream_t)stream, &h->err);
+    if (h->wrap) return fail(h, GCM_ERR_STATE, "step_boundary: handle is not a latitude band");
+    hipStream_t s = (hipStream_t)stream;
+    if (h->H <= 2 * kGhost) {
+        step_rows(h, dt, 0, h->H, s);
+    } else {
+        step_rows(h, dt, 0, kGhost, s);
+        step_rows(h, dt, h->H - kGhost, h->H, s);
+    }
+    swap_state(h);
+    h->star_valid = false;
+    HIPCHK(h, hipGetLastError());
+    return GCM_OK;
+}
+
+int gcm_half_step(gcm_handle *h, int stage, double dt) {
+    if (!h || (stage != 0 && stage != 1)) return GCM_ERR_ARG;
+    if (h->pe) return pe25d_half(h->pe, stage, dt, h->stream, &h->err);
+    if (!h->wrap) return fail(h, GCM_ERR_UNSUPPORTED, "half_step on a latitude band");
+    if (stage == 0) {
+        staged_stage(h, 0, dt, 0, h->H, h->stream);
+        h->star_valid = true;
+    } else {
+        if (!h->star_valid) return fail(h, GCM_ERR_STATE, "half_step(1) before half_step(0)");
+        staged_stage(h, 1, dt, 0, h->H, h->stream);
+        staged_tracer(h, dt, 0, h->H, h->stream);
+        swap_state(h);
+        h->star_valid = false;
+    }
+    HIPCHK(h, hipGetLastError());
+    return GCM_OK;
+}
+
+// ------------------------------------------------------------------ ghost rows
+size_t gcm_halo_bytes(const gcm_handle *h) {
+    if (!h) return 0;
+    if (h->pe) return pe25d_halo_bytes(h->pe);
+    int nf = 0;
+    for (int f = 0; f < GCM_NFIELDS; ++f) nf += h->has[f];
+    return (size_t)nf * kGhost * h->W * sizeof(double);
+}
+
+// side 0: rows [0, 2) -> buffer (they become the north neighbour's south ghost rows)
+// side 1: rows [H-2, H) -> buffer
+int gcm_halo_pack(gcm_handle *h, int side, void *dev_buf, void *stream) {
+    if (!h || !dev_buf || (side != 0 && side != 1)) return GCM_ERR_ARG;
+    if (h->pe) return pe25d_halo(h->pe, true, side, dev_buf, (hipStream_t)stream, &h->err);
+    double *b = (double *)dev_buf;
+    const size_t n = (size_t)kGhost * h->W;
+    for (int f = 0; f < GCM_NFIELDS; ++f) {
+        if (!h->has[f]) continue;
+        const double *src = side == 0 ? h->cur[f] : h->cur[f] + (size_t)(h->H - kGhost) * h->W;
+        launch_copy_rows(b, src, h->W, kGhost, (hipStream_t)stream);
+        b += n;
+    }
+    HIPCHK(h, hipGetLastError());
+    return GCM_OK;
+}
+
+// side 0: buffer -> ghost rows [-2, 0); side 1: buffer -> ghost rows [H, H+2)
+int gcm_halo_unpack(gcm_handle *h, int side, const void *dev_buf, void *stream) {
+    if (!h || !dev_buf || (side != 0 && side != 1)) return GCM_ERR_ARG;
+    if (h->pe) return pe25d_halo(h->pe, false, side, (void *)dev_buf, (hipStream_t)stream, &h->err);
+    const double *b = (const double *)dev_buf;
+    const size_t n = (size_t)kGhost * h->W;
+    for (int f = 0; f < GCM_NFIELDS; ++f) {
+        if (!h->has[f]) continue;
+        double *dst = side == 0 ? h->cur[f] - n : h->cur[f] + (size_t)h->H * h->W;
+        launch_copy_rows(dst, b, h->W, kGhost, (hipStream_t)stream);
+        b += n;
+    }
+    HIPCHK(h, hipGetLastError());
+    return GCM_OK;
+}
+
+int gcm_sync(gcm_handle *h) {
+    if (!h) return GCM_ERR_ARG;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return GCM_OK;
+}
+
+// ------------------------------------------------------------------ diagnostics
+}  // extern "C"
+
+__global__ __launch_bounds__(256) void diag_kernel(const double *x, long n, double *out) {
+    // out[4*b + {0,1,2,3}] = max, min, sum, nan-count of this block's grid-stride share
+    double mx = -INFINITY, mn = INFINITY, sm = 0.0, nn = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const double v = x[i];
+        if (v != v) nn += 1.0;
+        mx = fmax(mx, v);
+        mn = fmin(mn, v);
+        sm += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = fmax(mx, __shfl_down(mx, o));
+        mn = fmin(mn, __shfl_down(mn, o));
+        sm += __shfl_down(sm, o);
+        nn += __shfl_down(nn, o);
+    }
+    __shared__ double s[4][4];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s[w][0] = mx;
+        s[w][1] = mn;
+        s[w][2] = sm;
+        s[w][3] = nn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            s[0][0] = fmax(s[0][0], s[k][0]);
+            s[0][1] = fmin(s[0][1], s[k][1]);
+            s[0][2] += s[k][2];
+            s[0][3] += s[k][3];
+        }
+        for (int k = 0; k < 4; ++k) out[4 * blockIdx.x + k] = s[0][k];
+    }
+}
+
+extern "C" {
+
+int gcm_diag(gcm_handle *h, int kind, double *out) {
+    if (!h || !out) return GCM_ERR_ARG;
+    const double *x = nullptr;
+    long n = (long)h->H * h->W;
+    int f;
+    switch (kind) {
+        case GCM_DIAG_ANY_NAN: case GCM_DIAG_MAX_U: case GCM_DIAG_MIN_U: f = GCM_U; break;
+        case GCM_DIAG_MEAN_P: case GCM_DIAG_SUM_P: f = GCM_P; break;
+        case GCM_DIAG_MAX_V: case GCM_DIAG_MIN_V: f = GCM_V; break;
+        default: return fail(h, GCM_ERR_ARG, "gcm_diag: unknown kind");
+    }
+    if (h->pe) {
+        x = pe25d_field(h->pe, f, &n);
+    } else {
+        x = h->cur[f];
+    }
+    const int nb = gcm_handle::kDiagBlocks;
+    hipLaunchKernelGGL(diag_kernel, dim3(nb), dim3(256), 0, h->stream, x, n, h->diag_dev);
+    std::vector<double> part(4 * nb);
+    HIPCHK(h, hipMemcpyAsync(part.data(), h->diag_dev, sizeof(double) * 4 * nb,
+                             hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double mx = -INFINITY, mn = INFINITY, sm = 0.0, nn = 0.0;
+    for (int b = 0; b < nb; ++b) {
+        mx = std::fmax(mx, part[4 * b]);
+        mn = std::fmin(mn, part[4 * b + 1]);
+        sm += part[4 * b + 2];
+        nn += part[4 * b + 3];
+    }
+    switch (kind) {
+        case GCM_DIAG_ANY_NAN: *out = nn > 0 ? 1.0 : 0.0; break;
+        case GCM_DIAG_MAX_U: case GCM_DIAG_MAX_V: *out = nn > 0 ? NAN : mx; break;
+        case GCM_DIAG_MIN_U: case GCM_DIAG_MIN_V: *out = nn > 0 ? NAN : mn; break;
+        case GCM_DIAG_MEAN_P: *out = sm / (double)n; break;
+        case GCM_DIAG_SUM_P: *out = sm; break;
+    }
+    return GCM_OK;
+}
+
+int gcm_time_steps(gcm_handle *h, int nsteps, double dt, double *ms, double *kernel_ms_avg) {
+    if (!h || nsteps < 1 || !ms) return GCM_ERR_ARG;
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    HIPCHK(h, hipEventRecord(e0, h->stream));
+    int rc = gcm_step(h, nsteps, dt);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(e1, h->stream));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float t = 0;
+    HIPCHK(h, hipEventElapsedTime(&t, e0, e1));
+    *ms = t;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (kernel_ms_avg) {
+        // second pass: one event pair around every launch of the dominant kernel
+        const size_t need = 2 * (size_t)nsteps;
+        while (h->ev.size() < need) {
+            hipEvent_t e;
+            HIPCHK(h, hipEventCreate(&e));
+            h->ev.push_back(e);
+        }
+        h->ev_used = 0;
+        h->timing = true;
+        if (h->pe) pe25d_timing(h->pe, &h->ev, &h->ev_used);
+        rc = gcm_step(h, nsteps, dt);
+        h->timing = false;
+        if (h->pe) pe25d_timing(h->pe, nullptr, nullptr);
+        if (rc) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        double tot = 0;
+        int cnt = 0;
+        for (size_t k = 0; k + 1 < h->ev_used; k += 2) {
+            float d = 0;
+            HIPCHK(h, hipEventElapsedTime(&d, h->ev[k], h->ev[k + 1]));
+            tot += d;
+            ++cnt;
+        }
+        *kernel_ms_avg = cnt ? tot / cnt : 0.0;
+    }
+    return GCM_OK;
+}
+
+}  // extern "C"

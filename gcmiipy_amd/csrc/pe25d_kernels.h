@@ -1,0 +1,29 @@
+// 2.5-D sigma-level primitive equations (GCM_PE25D): host-visible interface of
+// pe25d_kernels.hip, used by gcmcore.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/gcmcore.h"
+
+namespace gcm {
+
+struct Pe25d;
+
+Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t s, std::string *err);
+void pe25d_destroy(Pe25d *m);
+int pe25d_set(Pe25d *m, bool star, const double *p, const double *u, const double *v,
+              const double *t, const double *q, std::string *err);
+int pe25d_get(Pe25d *m, bool star, double *p, double *u, double *v, double *t, double *q,
+              std::string *err);
+int pe25d_step(Pe25d *m, double dt, hipStream_t s, std::string *err);
+int pe25d_step_part(Pe25d *m, int part, double dt, hipStream_t s, std::string *err);
+int pe25d_half(Pe25d *m, int stage, double dt, hipStream_t s, std::string *err);
+size_t pe25d_halo_bytes(const Pe25d *m);
+int pe25d_halo(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s, std::string *err);
+const double *pe25d_field(Pe25d *m, int field, long *n);
+void pe25d_timing(Pe25d *m, std::vector<hipEvent_t> *ev, size_t *used);
+
+}  // namespace gcm

@@ -1,0 +1,38 @@
+// Kernel argument block + launch prototypes for the 2-D shallow-water family
+// (GCM_SW2D, GCM_SW2D_TEMP [+ tracer]).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gcm {
+
+constexpr int kGhost = 2;        // ghost rows on each side of a latitude band
+constexpr int kStripCols = 60;   // output columns per wave in the fused kernel (64 lanes - 2x2 halo)
+constexpr int kWavesPerBlock = 4;
+
+// Pointers address interior row 0; with wrap_j == 0 rows -2,-1 and H,H+1 are ghost rows.
+struct Sw2dArgs {
+    const double *bu, *bv, *bp, *bt, *bq;   // base (time n) state
+    const double *su, *sv, *sp, *st;        // stage state the tendencies are evaluated on
+    const double *sgeo, *sirho, *sst;       // staged TEMP: derived fields of the stage state
+    double *ou, *ov, *op, *ot, *oq;         // output
+    double *dgeo, *dirho, *dst;             // derive kernel outputs
+    int W, H;                               // columns, rows owned
+    int wrap_j;                             // 1: rows wrap modulo H (single band); 0: ghost rows
+    int j0, j1;                             // row range [j0, j1) to produce
+    int rows_per_band;                      // fused: output rows per wave
+    double dt, dx, inv_dx, dx2, inv_dx2;
+};
+
+// staged variant
+void launch_sw2d_stage(const Sw2dArgs &a, bool temp, hipStream_t s);
+void launch_sw2d_derive(const Sw2dArgs &a, hipStream_t s);            // p,t -> geo, 1/rho, scaled_t
+void launch_tracer_axis(const Sw2dArgs &a, int axis, bool limit, const double *q_in,
+                        double *q_out, hipStream_t s);
+// fused variant: predictor + corrector (+ both tracer passes) in one launch
+void launch_sw2d_fused(const Sw2dArgs &a, bool temp, int tracer, hipStream_t s);
+int sw2d_fused_rows_per_band(int W, int H);
+
+// ghost rows for a single band that is stepped with wrap_j == 0 (tests) and halo pack/unpack
+void launch_copy_rows(double *dst, const double *src, int W, int nrows, hipStream_t s);
+
+}  // namespace gcm

@@ -1,0 +1,349 @@
+// HIP kernels for the 2-D shallow-water family on the doubly periodic C-grid:
+//   GCM_SW2D       matsuno_c_grid.matsumo_scheme   (matsuno_c_grid.py:125-142)
+//   GCM_SW2D_TEMP  matsumo_temp.matsumo_scheme     (matsumo_temp.py:66-99)
+//   tracer         two_d.finite_volume_advection   (two_d.py:198-207) [+ van Leer]
+//
+// Two variants of the same arithmetic (gcm_math.h):
+//   staged  one thread per cell, one launch per Euler stage, neighbours through L1/L2;
+//           the predicted ("star") state is materialised in HBM.
+//   fused   one wave marches down a 60-column strip keeping a 3-row window of the
+//           base state and of the predicted state in registers; i+-1 neighbours come
+//           from wave64 DPP shifts; predictor and corrector (and both tracer passes)
+//           run in one launch, so every field is read once and written once per step.
+#include "sw2d_kernels.h"
+
+#include <cstdlib>
+
+#include "gcm_math.h"
+
+namespace gcm {
+
+__device__ __forceinline__ long row_off(int j, int H, int W, bool wrap) {
+    if (wrap) {
+        j %= H;
+        if (j < 0) j += H;
+    }
+    return (long)j * W;
+}
+
+// ------------------------------------------------------------------ staged
+__global__ __launch_bounds__(256) void sw2d_derive_kernel(Sw2dArgs a) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = a.j0 + blockIdx.y * 4 + threadIdx.y;
+    if (i >= a.W || j >= a.j1) return;
+    const long o = (long)j * a.W + i;
+    Thermo th = thermo(a.sp[o], a.st[o], a.dx2);
+    a.dgeo[o] = th.geo;
+    a.dirho[o] = th.inv_rho;
+    a.dst[o] = th.st;
+}
+
+template <bool TEMP>
+__global__ __launch_bounds__(256) void sw2d_stage_kernel(Sw2dArgs a) {
+    const int W = a.W, H = a.H;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = a.j0 + blockIdx.y * 4 + threadIdx.y;
+    if (i >= W || j >= a.j1) return;
+    const bool wrap = a.wrap_j;
+    const int iw = i == 0 ? W - 1 : i - 1, ie = i == W - 1 ? 0 : i + 1;
+    const long rc = row_off(j, H, W, wrap), rn = row_off(j - 1, H, W, wrap),
+               rs = row_off(j + 1, H, W, wrap);
+    const double uc = a.su[rc + i], uw = a.su[rc + iw], ue = a.su[rc + ie], un = a.su[rn + i],
+                 us = a.su[rs + i], usw = a.su[rs + iw];
+    const double vc = a.sv[rc + i], vw = a.sv[rc + iw], ve = a.sv[rc + ie], vn = a.sv[rn + i],
+                 vs = a.sv[rs + i], vsw = a.sv[rs + iw];
+    const double pc = a.sp[rc + i], pw = a.sp[rc + iw], pe = a.sp[rc + ie], pn = a.sp[rn + i],
+                 ps = a.sp[rs + i];
+    double gc = pc, ge = pe, gs = ps;
+    if (TEMP) {
+        gc = a.sgeo[rc + i];
+        ge = a.sgeo[rc + ie];
+        gs = a.sgeo[rs + i];
+    }
+    double du = adv_vel_u(uc, uw, ue, un, us, vc, vw, vs, vsw, a.inv_dx) + geo_grad(ge, gc, a.inv_dx);
+    double dv = adv_vel_v(vc, vw, ve, vn, vs, uc, un, uw, usw, a.inv_dx) + geo_grad(gs, gc, a.inv_dx);
+    if (TEMP) {
+        const double vis = visc_u(uc, uw, ue, un, us, a.inv_dx2) * a.sirho[rc + i];
+        du -= vis;
+        dv -= vis;  // the v equation uses the viscosity of u, matsumo_temp.py:75,91
+    }
+    const double dp = adv_geo(uc, uw, vc, vn, pc, pw, pe, pn, ps, a.inv_dx);
+    const long o = (long)j * W + i;
+    const double bp = a.bp[o];
+    const double pnew = bp - a.dt * dp;
+    a.ou[o] = a.bu[o] - a.dt * du;
+    a.ov[o] = a.bv[o] - a.dt * dv;
+    a.op[o] = pnew;
+    if (TEMP) {
+        const double dst = adv_geo(uc, uw, vc, vn, a.sst[rc + i], a.sst[rc + iw], a.sst[rc + ie],
+                                   a.sst[rn + i], a.sst[rs + i], a.inv_dx);
+        const double tt = bp * a.bt[o] * a.dx2 - a.dt * dst;
+        a.ot[o] = tt * rcp(pnew * a.dx2);  // unscaling, matsumo_temp.py:33-35
+    }
+}
+
+// one axis of the dimension-split tracer step (two_d.py:103-116), axis 0 = j with V[0] = v,
+// axis 1 = i with V[1] = u
+template <int AXIS, bool LIMIT>
+__global__ __launch_bounds__(256) void tracer_axis_kernel(Sw2dArgs a, const double *qin,
+                                                           double *qout) {
+    const int W = a.W, H = a.H;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int j = a.j0 + blockIdx.y * 4 + threadIdx.y;
+    if (i >= W || j >= a.j1) return;
+    const bool wrap = a.wrap_j;
+    double f, fm;
+    const long rc = row_off(j, H, W, wrap);
+    if (AXIS == 0) {
+        const long r1 = row_off(j + 1, H, W, wrap), r2 = row_off(j + 2, H, W, wrap),
+                   rm = row_off(j - 1, H, W, wrap), rmm = row_off(j - 2, H, W, wrap);
+        const double qmm = qin[rmm + i], qm = qin[rm + i], q0 = qin[rc + i], q1 = qin[r1 + i],
+                     q2 = qin[r2 + i];
+        f = face_flux<LIMIT>(a.bv[rc + i], qm, q0, q1, q2, a.dt, a.inv_dx);
+        fm = face_flux<LIMIT>(a.bv[rm + i], qmm, qm, q0, q1, a.dt, a.inv_dx);
+        qout[(long)j * W + i] = q0 - f + fm;
+    } else {
+        auto wi = [W](int x) { x %= W; return x < 0 ? x + W : x; };
+        const int i1 = wi(i + 1), i2 = wi(i + 2), im = wi(i - 1), imm = wi(i - 2);
+        const double qmm = qin[rc + imm], qm = qin[rc + im], q0 = qin[rc + i], q1 = qin[rc + i1],
+                     q2 = qin[rc + i2];
+        f = face_flux<LIMIT>(a.bu[rc + i], qm, q0, q1, q2, a.dt, a.inv_dx);
+        fm = face_flux<LIMIT>(a.bu[rc + im], qmm, qm, q0, q1, a.dt, a.inv_dx);
+        qout[(long)j * W + i] = q0 - f + fm;
+    }
+}
+
+static dim3 cell_grid(const Sw2dArgs &a) {
+    return dim3((a.W + 63) / 64, (a.j1 - a.j0 + 3) / 4);
+}
+
+void launch_sw2d_derive(const Sw2dArgs &a, hipStream_t s) {
+    if (a.j1 <= a.j0) return;
+    hipLaunchKernelGGL(sw2d_derive_kernel, cell_grid(a), dim3(64, 4), 0, s, a);
+}
+
+void launch_sw2d_stage(const Sw2dArgs &a, bool temp, hipStream_t s) {
+    if (a.j1 <= a.j0) return;
+    if (temp)
+        hipLaunchKernelGGL(sw2d_stage_kernel<true>, cell_grid(a), dim3(64, 4), 0, s, a);
+    else
+        hipLaunchKernelGGL(sw2d_stage_kernel<false>, cell_grid(a), dim3(64, 4), 0, s, a);
+}
+
+void launch_tracer_axis(const Sw2dArgs &a, int axis, bool limit, const double *q_in,
+                        double *q_out, hipStream_t s) {
+    if (a.j1 <= a.j0) return;
+    dim3 g = cell_grid(a), b(64, 4);
+    if (axis == 0) {
+        if (limit) hipLaunchKernelGGL((tracer_axis_kernel<0, true>), g, b, 0, s, a, q_in, q_out);
+        else hipLaunchKernelGGL((tracer_axis_kernel<0, false>), g, b, 0, s, a, q_in, q_out);
+    } else {
+        if (limit) hipLaunchKernelGGL((tracer_axis_kernel<1, true>), g, b, 0, s, a, q_in, q_out);
+        else hipLaunchKernelGGL((tracer_axis_kernel<1, false>), g, b, 0, s, a, q_in, q_out);
+    }
+}
+
+// ------------------------------------------------------------------ fused
+// One row of a state (base or predicted) as a lane keeps it: own column plus the
+// west neighbour of u and v (needed while the row is the window's south or centre
+// row) and, for TEMP, the derived fields.
+struct Row {
+    double u, uw, v, vw, p, st, g, irho;
+};
+
+template <bool TEMP>
+__device__ __forceinline__ Row make_row(double u, double v, double p, double t, double dx2) {
+    Row r;
+    r.u = u;
+    r.v = v;
+    r.p = p;
+    r.uw = from_west(u);
+    r.vw = from_west(v);
+    if (TEMP) {
+        Thermo th = thermo(p, t, dx2);
+        r.st = th.st;
+        r.g = th.geo;
+        r.irho = th.inv_rho;
+    } else {
+        r.st = 0.0;
+        r.g = p;
+        r.irho = 0.0;
+    }
+    return r;
+}
+
+struct Tend {
+    double du, dv, dp, dst;
+};
+
+// tendencies at the centre row R0 of a 3-row window (north RM, south RP)
+template <bool TEMP>
+__device__ __forceinline__ Tend tendencies(const Row &RM, const Row &R0, const Row &RP,
+                                           double inv_dx, double inv_dx2) {
+    const double ue = from_east(R0.u), ve = from_east(R0.v);
+    const double pw = from_west(R0.p), pe = from_east(R0.p);
+    const double ge = TEMP ? from_east(R0.g) : pe;
+    Tend t;
+    t.du = adv_vel_u(R0.u, R0.uw, ue, RM.u, RP.u, R0.v, R0.vw, RP.v, RP.vw, inv_dx) +
+           geo_grad(ge, R0.g, inv_dx);
+    t.dv = adv_vel_v(R0.v, R0.vw, ve, RM.v, RP.v, R0.u, RM.u, R0.uw, RP.uw, inv_dx) +
+           geo_grad(RP.g, R0.g, inv_dx);
+    if (TEMP) {
+        const double vis = visc_u(R0.u, R0.uw, ue, RM.u, RP.u, inv_dx2) * R0.irho;
+        t.du -= vis;
+        t.dv -= vis;
+    }
+    t.dp = adv_geo(R0.u, R0.uw, R0.v, RM.v, R0.p, pw, pe, RM.p, RP.p, inv_dx);
+    t.dst = 0.0;
+    if (TEMP) {
+        const double stw = from_west(R0.st), ste = from_east(R0.st);
+        t.dst = adv_geo(R0.u, R0.uw, R0.v, RM.v, R0.st, stw, ste, RM.st, RP.st, inv_dx);
+    }
+    return t;
+}
+
+template <bool TEMP, int TRACER, bool WRAPJ>
+__global__ __launch_bounds__(256) void sw2d_fused_kernel(Sw2dArgs a) {
+    const int W = a.W, H = a.H;
+    const int lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int i0 = strip * kStripCols;
+    if (i0 >= W) return;  // wave-uniform; the kernel has no barriers
+    const int ja = a.j0 + blockIdx.y * a.rows_per_band;
+    const int jb = min(ja + a.rows_per_band, a.j1);
+    if (ja >= jb) return;
+    const int col = i0 - 2 + lane;
+    int ci = col % W;
+    if (ci < 0) ci += W;
+    const bool store_lane = lane >= 2 && lane < 62 && col < W;
+    const double dt = a.dt, inv_dx = a.inv_dx, inv_dx2 = a.inv_dx2, dx2 = a.dx2;
+
+    struct Raw {
+        double u, v, p, t, q;
+    };
+    auto load = [&](int j) {
+        const long o = row_off(j, H, W, WRAPJ) + ci;
+        Raw r;
+        r.u = a.bu[o];
+        r.v = a.bv[o];
+        r.p = a.bp[o];
+        r.t = TEMP ? a.bt[o] : 0.0;
+        r.q = TRACER ? a.bq[o] : 0.0;
+        return r;
+    };
+
+    Raw x = load(ja - 2);
+    Row BM = make_row<TEMP>(x.u, x.v, x.p, x.t, dx2);
+    double qmm = 0.0, qm = x.q;
+    x = load(ja - 1);
+    Row B0 = make_row<TEMP>(x.u, x.v, x.p, x.t, dx2);
+    double q0 = x.q;
+    x = load(ja);
+    Row BP = make_row<TEMP>(x.u, x.v, x.p, x.t, dx2);
+    double qp = x.q;
+    Raw nxt = load(ja + 1);
+    Row SM, S0, SP;
+    SM = S0 = SP = BM;  // overwritten before first use
+    double f0_prev = 0.0;
+
+    for (int r = ja - 1; r <= jb; ++r) {
+        // ---- predictor: star row r from base rows r-1, r, r+1
+        {
+            const Tend t = tendencies<TEMP>(BM, B0, BP, inv_dx, inv_dx2);
+            const double us = B0.u - dt * t.du;
+            const double vs = B0.v - dt * t.dv;
+            const double ps = B0.p - dt * t.dp;
+            double ts = 0.0;
+            if (TEMP) ts = (B0.st - dt * t.dst) * rcp(ps * dx2);
+            SM = S0;
+            S0 = SP;
+            SP = make_row<TEMP>(us, vs, ps, ts, dx2);
+        }
+        // ---- tracer, axis 0 flux through the face between rows r-1 and r
+        double f0_cur = 0.0;
+        if (TRACER && r >= ja)
+            f0_cur = face_flux<TRACER == 2>(BM.v, qmm, qm, q0, qp, dt, inv_dx);
+        // ---- corrector: output row r-1 from star rows r-2, r-1, r and base row r-1
+        if (r >= ja + 1) {
+            const Tend t = tendencies<TEMP>(SM, S0, SP, inv_dx, inv_dx2);
+            const double un = BM.u - dt * t.du;
+            const double vn = BM.v - dt * t.dv;
+            const double pn = BM.p - dt * t.dp;
+            double tn = 0.0, qn = 0.0;
+            if (TEMP) tn = (BM.st - dt * t.dst) * rcp(pn * dx2);
+            if (TRACER) {
+                const double qs = qm - f0_cur + f0_prev;  // after the axis-0 pass
+                const double qs_w = from_west(qs), qs_e = from_east(qs);
+                const double qs_ee = from_east(qs_e);
+                const double f1 = face_flux<TRACER == 2>(BM.u, qs_w, qs, qs_e, qs_ee, dt, inv_dx);
+                qn = qs - f1 + from_west(f1);
+            }
+            if (store_lane) {
+                const long o = (long)(r - 1) * W + col;
+                a.ou[o] = un;
+                a.ov[o] = vn;
+                a.op[o] = pn;
+                if (TEMP) a.ot[o] = tn;
+                if (TRACER) a.oq[o] = qn;
+            }
+        }
+        // ---- slide the windows one row south
+        f0_prev = f0_cur;
+        BM = B0;
+        B0 = BP;
+        BP = make_row<TEMP>(nxt.u, nxt.v, nxt.p, nxt.t, dx2);
+        qmm = qm;
+        qm = q0;
+        q0 = qp;
+        qp = nxt.q;
+        if (r + 3 <= jb + 1) nxt = load(r + 3);
+    }
+}
+
+int sw2d_fused_rows_per_band(int W, int H) {
+    if (const char *e = getenv("GCM_FUSED_ROWS")) {
+        int v = atoi(e);
+        if (v > 0) return v;
+    }
+    const int strips = (W + kStripCols - 1) / kStripCols;
+    const int bands_wanted = (4096 + strips - 1) / strips;  // >= 16 waves per CU
+    int rpb = H / bands_wanted;
+    if (rpb < 8) rpb = 8;
+    if (rpb > 64) rpb = 64;
+    return rpb;
+}
+
+template <bool TEMP, int TRACER>
+static void launch_fused_t(const Sw2dArgs &a, dim3 g, hipStream_t s) {
+    if (a.wrap_j)
+        hipLaunchKernelGGL((sw2d_fused_kernel<TEMP, TRACER, true>), g, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((sw2d_fused_kernel<TEMP, TRACER, false>), g, dim3(256), 0, s, a);
+}
+
+void launch_sw2d_fused(const Sw2dArgs &a, bool temp, int tracer, hipStream_t s) {
+    if (a.j1 <= a.j0) return;
+    const int strips = (a.W + kStripCols - 1) / kStripCols;
+    dim3 g((strips + kWavesPerBlock - 1) / kWavesPerBlock,
+           (a.j1 - a.j0 + a.rows_per_band - 1) / a.rows_per_band);
+    if (!temp) launch_fused_t<false, 0>(a, g, s);
+    else if (tracer == 0) launch_fused_t<true, 0>(a, g, s);
+    else if (tracer == 1) launch_fused_t<true, 1>(a, g, s);
+    else launch_fused_t<true, 2>(a, g, s);
+}
+
+__global__ void copy_rows_kernel(double *dst, const double *src, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+void launch_copy_rows(double *dst, const double *src, int W, int nrows, hipStream_t s) {
+    const long n = (long)W * nrows;
+    if (n <= 0) return;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(blocks), dim3(256), 0, s, dst, src, n);
+}
+
+}  // namespace gcm

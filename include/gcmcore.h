@@ -1,0 +1,172 @@
+/* gcmcore.h -- C ABI of libgcmcore.so, the MI355X-native Matsuno C-grid
+ * dynamical core for gcmiipy.
+ *
+ * The reference (marthinwurer/gcmiipy) is pure Python/NumPy and has no FFI of
+ * its own; the entry points below are what a ctypes binding for its time-step
+ * functions needs (INTEGRATION.md shows that binding).  Each one names the
+ * reference interface it stands behind.  Plain pointers and sizes only; no
+ * torch / numpy types.  Every function returns 0 on success or a negative
+ * gcm_status; nothing throws across the ABI; the message of the last failure
+ * is available from gcm_last_error().
+ *
+ * Threading: a handle is driven by one host thread at a time.  Calls that
+ * launch work (gcm_step, gcm_half_step, gcm_halo_*) are asynchronous on the
+ * handle's stream; gcm_get_state / gcm_diag / gcm_sync synchronise.
+ *
+ * Memory: all arrays are float64, C-contiguous, reference layout:
+ *   2-D fields [j][i]   (H rows x W columns, i fastest)
+ *   3-D fields [k][j][i] (L levels, k = 0 is the bottom layer)
+ * Host buffers stay caller-owned and are only touched inside set/get calls.
+ */
+#ifndef GCMCORE_H
+#define GCMCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCM_ABI_VERSION 1
+
+typedef struct gcm_handle gcm_handle;
+
+typedef enum {
+    GCM_OK = 0,
+    GCM_ERR_ARG = -1,      /* bad argument / shape (mirrors the reference's shape asserts) */
+    GCM_ERR_HIP = -2,      /* a HIP runtime call failed                                     */
+    GCM_ERR_NODEVICE = -3, /* no gfx950 device visible: there is NO CPU fallback            */
+    GCM_ERR_STATE = -4,    /* call sequence error (e.g. half_step corrector before predictor) */
+    GCM_ERR_UNSUPPORTED = -5
+} gcm_status;
+
+/* Which reference time-step the handle integrates. */
+typedef enum {
+    GCM_SW2D = 1,      /* matsuno_c_grid.matsumo_scheme(u,v,p,dx,dt)        matsuno_c_grid.py:125-142 */
+    GCM_SW2D_TEMP = 2, /* matsumo_temp.matsumo_scheme(u,v,p,t,dx,dt)        matsumo_temp.py:66-99
+                          (+ optional tracer q, two_d.py:198-207 / flux_limiter.py:10-32)            */
+    GCM_PE2D = 3,      /* no_limits_2d.matsuno_timestep(p,u,v,t,q,dt,dx)    no_limits_2d.py:129-131   */
+    GCM_PE25D = 4      /* dynamics.matsuno_timestep(p,u,v,t,q,dt,geom)      dynamics.py:230-237       */
+} gcm_model;
+
+typedef enum { GCM_P = 0, GCM_U = 1, GCM_V = 2, GCM_T = 3, GCM_Q = 4, GCM_NFIELDS = 5 } gcm_field;
+
+/* Tracer scheme carried by GCM_SW2D_TEMP alongside the dynamics (advected by
+ * the time-n winds, V = (v, u) in two_d.py's axis convention). */
+typedef enum {
+    GCM_TRACER_NONE = 0,
+    GCM_TRACER_UPWIND = 1,  /* two_d.finite_volume_advection            two_d.py:198-207          */
+    GCM_TRACER_VANLEER = 2  /* the same split step with van_leer(calc_r) limiting of the centred
+                               flux (flux_limiter.py:10-20, two_d.py:135-149); composition by this
+                               build, see DESIGN.md                                               */
+} gcm_tracer;
+
+/* Kernel variant (same arithmetic, different data movement). */
+typedef enum {
+    GCM_VARIANT_AUTO = 0,
+    GCM_VARIANT_STAGED = 1, /* one launch per Matsuno stage, predicted state materialised in HBM */
+    GCM_VARIANT_FUSED = 2   /* predictor + corrector in one launch, predicted state in registers */
+} gcm_variant;
+
+typedef struct {
+    int32_t abi_version;   /* GCM_ABI_VERSION */
+    int32_t model;         /* gcm_model */
+    int32_t width;         /* W: cells along i (longitude), contiguous                          */
+    int32_t height;        /* H: rows along j owned by THIS handle (a latitude band if nranks>1) */
+    int32_t layers;        /* L: sigma levels (GCM_PE25D), else 1                                */
+    int32_t tracer;        /* gcm_tracer (GCM_SW2D_TEMP only)                                    */
+    int32_t variant;       /* gcm_variant                                                        */
+    int32_t filter;        /* GCM_PE25D: 1 = apply low_pass.arakawa_1977 (low_pass.py:41-78)     */
+    /* Latitude-band decomposition.  nranks == 1: the handle owns the whole grid
+     * and np.roll's pole-to-pole periodicity along j is done by index arithmetic.  nranks > 1:
+     * rows [row0, row0+height) of a global_height-row grid; the two ghost rows on either side
+     * are filled by the caller between steps through gcm_halo_* (RCCL ring incl. the wrap).    */
+    int32_t nranks;
+    int32_t rank;
+    int32_t global_height;
+    int32_t row0;
+    int32_t device;        /* HIP device ordinal; -1 = current                                   */
+    int32_t reserved0;
+    double dx;             /* scalar grid spacing in metres (2-D models: both axes)              */
+    double dy;             /* GCM_PE25D: geom.dy                            geometry.py:138      */
+    double ptop;           /* GCM_PE25D: geom.ptop in Pa                    geometry.py:147      */
+    /* GCM_PE25D host tables, copied at create (geometry.py:79-85,136-137,149): */
+    const double *dx_j;    /* [global_height]  zonal spacing at cell-centre latitudes            */
+    const double *dx_h;    /* [global_height]  zonal spacing at v latitudes                      */
+    const double *sig;     /* [L] */
+    const double *dsig;    /* [L] */
+    const double *sigb;    /* [L] */
+    const double *sigt;    /* [L] */
+    const double *heightmap; /* [height][W] rows of THIS band, or NULL for flat topography       */
+    void *stream;          /* hipStream_t to launch on; NULL = the null stream                   */
+} gcm_config;
+
+/* Library / device probes (no handle needed). */
+int gcm_abi_version(void);
+int gcm_device_count(void);                 /* gfx950 devices visible; 0 on a CPU-only box */
+const char *gcm_build_info(void);           /* compiler, offload arch, build flags          */
+
+/* Lifetime.  Device buffers are library-owned inside the handle. */
+int gcm_create(const gcm_config *cfg, gcm_handle **out);
+int gcm_destroy(gcm_handle *h);
+const char *gcm_last_error(const gcm_handle *h); /* h may be NULL: last create() failure */
+
+/* State transfer (host <-> device).  NULL pointers are skipped.  Fields a model
+ * does not have must be NULL.  2-D models: all five are [H][W]; GCM_PE25D: p is
+ * [H][W], the rest [L][H][W].  Reference tuple orders: (u,v,p[,t]) for the
+ * shallow-water schemes, (p,u,v,t,q) for the primitive-equation ones.          */
+int gcm_set_state(gcm_handle *h, const double *p, const double *u, const double *v,
+                  const double *t, const double *q);
+int gcm_get_state(gcm_handle *h, double *p, double *u, double *v, double *t, double *q);
+
+/* One or more full Matsuno steps (predictor + corrector), state stays resident.
+ * Stands behind matsumo_scheme / matsuno_timestep (files cited at gcm_model). */
+int gcm_step(gcm_handle *h, int nsteps, double dt);
+
+/* One Euler stage, for per-stage parity tests and for the reference's
+ * boundary_conditions hook (dynamics.py:232-236): stage == 0 computes the
+ * predictor from the current state into the handle's "star" buffers; stage == 1
+ * computes the corrector from (current, star) and makes it the current state.
+ * gcm_get_star / gcm_set_star expose the predicted state in between.
+ * Stands behind half_timestep (dynamics.py:183-227, no_limits_2d.py:104-126). */
+int gcm_half_step(gcm_handle *h, int stage, double dt);
+int gcm_get_star(gcm_handle *h, double *p, double *u, double *v, double *t, double *q);
+int gcm_set_star(gcm_handle *h, const double *p, const double *u, const double *v,
+                 const double *t, const double *q);
+
+/* Diagnostics the reference's drivers evaluate on the host every step
+ * (SURVEY.md 8f-1); computed by device reductions, result copied to *out. */
+typedef enum {
+    GCM_DIAG_ANY_NAN = 0,   /* np.isnan(u).any() watch            matsuno_c_grid.py:184-187     */
+    GCM_DIAG_MAX_U = 1,     /* np.max(u)                          constants.py:111-112          */
+    GCM_DIAG_MEAN_P = 2,    /* np.mean(p)                         constants.py:111-112          */
+    GCM_DIAG_SUM_P = 3,     /* conservation check                                                */
+    GCM_DIAG_MIN_U = 4, GCM_DIAG_MAX_V = 5, GCM_DIAG_MIN_V = 6  /* STATS, no_limits_2_5d.py:85-88 */
+} gcm_diag_kind;
+int gcm_diag(gcm_handle *h, int kind, double *out);
+
+/* Latitude-band ghost rows (nranks > 1).  The library packs the rows a neighbour
+ * needs into / unpacks them from caller-owned DEVICE buffers (e.g. torch tensors
+ * handed to torch.distributed / RCCL send-recv); it never calls a collective
+ * itself.  `side` 0 = towards row 0 (north), 1 = towards the last row (south).
+ * gcm_halo_bytes gives the buffer size for one side.                           */
+size_t gcm_halo_bytes(const gcm_handle *h);
+int gcm_halo_pack(gcm_handle *h, int side, void *dev_buf, void *stream);
+int gcm_halo_unpack(gcm_handle *h, int side, const void *dev_buf, void *stream);
+/* Step split for comm/compute overlap: rows that need no ghost data, then the rest. */
+int gcm_step_interior(gcm_handle *h, double dt, void *stream);
+int gcm_step_boundary(gcm_handle *h, double dt, void *stream);
+
+int gcm_sync(gcm_handle *h);
+
+/* Timing helper for bench.py: runs nsteps steps bracketed by HIP events on the
+ * handle's stream; returns elapsed milliseconds in *ms and, in *kernel_ms_avg,
+ * the mean duration of the dominant kernel's launches measured by per-launch
+ * event pairs in a second pass (so the first figure carries no event overhead). */
+int gcm_time_steps(gcm_handle *h, int nsteps, double dt, double *ms, double *kernel_ms_avg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCMCORE_H */

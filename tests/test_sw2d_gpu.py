@@ -1,0 +1,176 @@
+"""GPU parity: HIP 2-D shallow-water path (through the C ABI) vs the oracle and
+the golden vectors.  Tolerance: 1e-10 relative (L-inf over max|field|), the
+figure BASELINE.json's north_star states; observed ~1e-15."""
+import numpy as np
+import pytest
+
+from conftest import golden, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+@pytest.fixture(scope="module")
+def g():
+    import gcmiipy_amd
+    assert gcmiipy_amd.device_count() >= 1, "no MI355X visible"
+    return gcmiipy_amd
+
+
+def _variants(g):
+    return (("fused", g._lib.VARIANT_FUSED), ("staged", g._lib.VARIANT_STAGED))
+
+
+def test_sw2d_golden_steps(g):
+    d = golden("g2_sw2d")
+    dx, dt = float(d["dx"]), float(d["dt"])
+    for name, var in _variants(g):
+        c = g.Core(g._lib.SW2D, 32, 16, dx=dx, variant=var)
+        c.set_state(p=d["p0"], u=d["u0"], v=d["v0"])
+        done = 0
+        for n in (1, 2, 10):
+            c.step(n - done, dt)
+            done = n
+            p, u, v, _, _ = c.get_state((0, 1, 2))
+            for k, x in zip("uvp", (u, v, p)):
+                e = rel_err(x, d["%s%d" % (k, n)])
+                assert e < TOL, (name, k, n, e)
+        c.close()
+
+
+def test_sw2d_dropin_and_main_ic(g):
+    """the reference call surface matsumo_scheme(u,v,p,dx,dt) on the reference's own
+    main() IC (matsuno_c_grid.py:145-158); inputs untouched, fresh outputs."""
+    from gcmiipy_amd.matsuno_c_grid import matsumo_scheme
+    d = golden("g2_sw2d")
+    u = np.zeros((64, 64)); v = np.zeros((64, 64)); p = np.full((64, 64), 8000.0)
+    u[32, 32] += 30
+    for _ in range(10):
+        keep = u.copy()
+        un, vn, pn = matsumo_scheme(u, v, p, 300e3, 300.0)
+        assert un is not u and np.array_equal(u, keep)
+        u, v, p = un, vn, pn
+    assert rel_err(u, d["main_u10"]) < TOL
+    assert rel_err(v, d["main_v10"]) < TOL
+    assert rel_err(p, d["main_p10"]) < TOL
+    assert abs(p.sum() - 32768000.0) < 1e-5          # flux form conserves sum(p)
+
+
+def test_sw2d_half_steps_match_full(g):
+    from oracle import sw2d
+    d = golden("g2_sw2d")
+    dx, dt = float(d["dx"]), float(d["dt"])
+    c = g.Core(g._lib.SW2D, 32, 16, dx=dx, variant=g._lib.VARIANT_STAGED)
+    c.set_state(p=d["p0"], u=d["u0"], v=d["v0"])
+    c.half_step(0, dt)
+    ps, us, vs, _, _ = c.get_star((0, 1, 2))
+    u0, v0, p0 = d["u0"], d["v0"], d["p0"]
+    assert rel_err(us, u0 - dt * (sw2d.advection_of_velocity_u(u0, v0, dx)
+                                  + sw2d.geopotential_gradient_u(p0, dx))) < TOL
+    assert rel_err(vs, v0 - dt * (sw2d.advection_of_velocity_v(u0, v0, dx)
+                                  + sw2d.geopotential_gradient_v(p0, dx))) < TOL
+    assert rel_err(ps, p0 - dt * sw2d.advection_of_geopotential(u0, v0, p0, dx)) < TOL
+    c.half_step(1, dt)
+    p, u, v, _, _ = c.get_state((0, 1, 2))
+    assert rel_err(u, d["u1"]) < TOL and rel_err(v, d["v1"]) < TOL and rel_err(p, d["p1"]) < TOL
+    with pytest.raises(g.GcmError):
+        c.half_step(1, dt)                              # corrector without predictor
+    c.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 7), (5, 1), (3, 5), (16, 61), (33, 130), (64, 64)])
+def test_sw2d_ragged_shapes_vs_oracle(g, shape):
+    """edge shapes: single row/column (every roll wraps onto itself), widths that are
+    not multiples of the 60-column strip, heights that are not multiples of a band."""
+    from oracle import sw2d
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    u, v = rng.standard_normal(shape), rng.standard_normal(shape)
+    p = 8000 + rng.standard_normal(shape)
+    dx, dt = 300e3, 300.0
+    ro = (u, v, p)
+    for _ in range(3):
+        ro = sw2d.matsumo_scheme(*ro, dx, dt)
+    for name, var in _variants(g):
+        c = g.Core(g._lib.SW2D, shape[1], shape[0], dx=dx, variant=var)
+        c.set_state(p=p, u=u, v=v)
+        c.step(3, dt)
+        pn, un, vn, _, _ = c.get_state((0, 1, 2))
+        c.close()
+        for k, x, y in zip("uvp", (un, vn, pn), ro):
+            assert rel_err(x, y) < TOL, (name, k, rel_err(x, y))
+
+
+def test_sw2d_temp_golden(g):
+    d = golden("g3_sw2d_temp")
+    dx, dt = float(d["dx"]), float(d["dt"])
+    for name, var in _variants(g):
+        c = g.Core(g._lib.SW2D_TEMP, 32, 16, dx=dx, variant=var)
+        c.set_state(p=d["p0"], u=d["u0"], v=d["v0"], t=d["t0"])
+        done = 0
+        for n in (1, 5):
+            c.step(n - done, dt)
+            done = n
+            p, u, v, t, _ = c.get_state((0, 1, 2, 3))
+            for k, x in zip("uvpt", (u, v, p, t)):
+                e = rel_err(x, d["%s%d" % (k, n)])
+                assert e < TOL, (name, k, n, e)
+        c.close()
+
+
+@pytest.mark.parametrize("scheme", ["upwind", "van_leer"])
+@pytest.mark.parametrize("shape", [(8, 12), (16, 61), (40, 200)])
+def test_sw2d_temp_tracer_vs_oracle(g, scheme, shape):
+    from oracle import sw2d_temp, tracer
+    rng = np.random.default_rng(7)
+    u, v = rng.standard_normal(shape), rng.standard_normal(shape)
+    p = 101325 + rng.standard_normal(shape)
+    t = 273.16 + rng.standard_normal(shape)
+    q = rng.random(shape)
+    q[2, 3] = q[2, 4] = q[3, 3]                         # exact-zero limiter denominators
+    u[1, 1] = 0.0                                        # strict `> 0` branch
+    dx, dt = 300e3, 300.0
+    ro, qo = (u, v, p, t), q
+    for _ in range(3):
+        V = np.stack([ro[1], ro[0]])                     # V[0] acts along j (two_d.py:16-22)
+        qo = tracer.limited_advection(dt, (dx, dx), V, qo, limiter=(scheme == "van_leer"))
+        ro = sw2d_temp.matsumo_scheme(*ro, dx, dt)
+    if scheme == "upwind":                               # pinned piece: equals the reference step
+        V = np.stack([v, u])
+        assert np.array_equal(tracer.limited_advection(dt, (dx, dx), V, q, limiter=False),
+                              tracer.finite_volume_advection(dt, (dx, dx), V, q))
+    tr = {"upwind": g._lib.TRACER_UPWIND, "van_leer": g._lib.TRACER_VANLEER}[scheme]
+    for name, var in _variants(g):
+        c = g.Core(g._lib.SW2D_TEMP, shape[1], shape[0], dx=dx, variant=var, tracer=tr)
+        c.set_state(p=p, u=u, v=v, t=t, q=q)
+        c.step(3, dt)
+        pn, un, vn, tn, qn = c.get_state()
+        c.close()
+        for k, x, y in zip("uvptq", (un, vn, pn, tn, qn), (*ro, qo)):
+            assert rel_err(x, y) < TOL, (name, scheme, k, rel_err(x, y))
+        assert abs(qn.sum() - q.sum()) < 1e-9 * q.size   # conservative
+
+
+def test_fused_equals_staged_full_size(g):
+    """BASELINE sizes: the two kernel variants share their arithmetic, so they must
+    agree to rounding on 720x360 and 4096x2048; sum(p) is conserved (flux form)."""
+    for (H, W, model, tr) in ((360, 720, g._lib.SW2D, 0), (2048, 4096, g._lib.SW2D_TEMP, 2)):
+        rng = np.random.default_rng(0)
+        u, v = rng.standard_normal((H, W)), rng.standard_normal((H, W))
+        p = (8000 if model == g._lib.SW2D else 101325) + rng.standard_normal((H, W))
+        t = 273.16 + rng.standard_normal((H, W))
+        q = rng.random((H, W))
+        res = []
+        for name, var in _variants(g):
+            c = g.Core(model, W, H, dx=300e3, variant=var, tracer=tr)
+            if model == g._lib.SW2D:
+                c.set_state(p=p, u=u, v=v)
+            else:
+                c.set_state(p=p, u=u, v=v, t=t, q=q)
+            c.step(3, 300.0)
+            res.append(c.get_state())
+            assert abs(c.diag(g._lib.DIAG_SUM_P) - p.sum()) < 1e-12 * abs(p.sum())
+            assert c.diag(g._lib.DIAG_ANY_NAN) == 0.0
+            c.close()
+        for a, b in zip(*res):
+            if a is not None:
+                assert rel_err(a, b) < 1e-13
