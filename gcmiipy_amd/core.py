@@ -91,6 +91,10 @@ class Core:
                 raise ValueError(msg)
             raise GcmError("gcm_create failed (%d): %s" % (rc, msg))
         self.is3d = model == _lib.PE25D
+        self.fields = {_lib.SW2D: (_lib.P, _lib.U, _lib.V),
+                       _lib.SW2D_TEMP: (_lib.P, _lib.U, _lib.V, _lib.T) +
+                       ((_lib.Q,) if tracer != _lib.TRACER_NONE else ()),
+                       }.get(model, (_lib.P, _lib.U, _lib.V, _lib.T, _lib.Q))
 
     # -- shapes ----------------------------------------------------------------
     def shape_of(self, field):
@@ -118,9 +122,9 @@ class Core:
         _check(fn(self._h, *[_ptr(x) for x in out]), self._h)
         return out
 
-    def get_state(self, fields=(_lib.P, _lib.U, _lib.V, _lib.T, _lib.Q)):
-        """-> [p, u, v, t, q] (None for fields not requested)"""
-        return self._get(lib.gcm_get_state, fields)
+    def get_state(self, fields=None):
+        """-> [p, u, v, t, q] (None for fields not requested / not in the model)"""
+        return self._get(lib.gcm_get_state, self.fields if fields is None else fields)
 
     def get_star(self, fields=(_lib.P, _lib.U, _lib.V, _lib.T)):
         return self._get(lib.gcm_get_star, fields)
