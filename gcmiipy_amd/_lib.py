@@ -41,6 +41,7 @@ SYMBOLS = {
     "gcm_abi_version": (C.c_int, []),
     "gcm_device_count": (C.c_int, []),
     "gcm_build_info": (C.c_char_p, []),
+    "gcm_exner_table": (C.c_int, [_dp]),
     "gcm_create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
     "gcm_destroy": (C.c_int, [_H]),
     "gcm_last_error": (C.c_char_p, [_H]),

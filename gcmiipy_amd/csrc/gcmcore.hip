@@ -32,6 +32,7 @@ struct gcm_handle {
     double *cur[GCM_NFIELDS] = {}, *nxt[GCM_NFIELDS] = {}, *star[GCM_NFIELDS] = {};
     double *geo = nullptr, *irho = nullptr, *sst = nullptr, *qtmp = nullptr;
     bool has[GCM_NFIELDS] = {};
+    double *exner_tab = nullptr;
     bool star_valid = false;
     int variant = GCM_VARIANT_FUSED;
     int rows_per_band = 32;
@@ -88,6 +89,12 @@ int gcm_device_count(void) {
 
 const char *gcm_build_info(void) {
     return "libgcmcore gfx950 (hipcc " __VERSION__ "), fp64, kernels: sw2d staged+fused, pe25d";
+}
+
+int gcm_exner_table(double *out256) {
+    if (!out256) return GCM_ERR_ARG;
+    build_exner_table(out256);
+    return GCM_OK;
 }
 
 const char *gcm_last_error(const gcm_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -160,7 +167,17 @@ int gcm_create(const gcm_config *cfg, gcm_handle **out) {
                 if ((rc = alloc_field(h, &h->sst))) return bail(rc, "");
             }
             if (h->has[GCM_Q] && (rc = alloc_field(h, &h->qtmp))) return bail(rc, "");
-            h->rows_per_band = sw2d_fused_rows_per_band(h->W, h->H);
+            if (temp) {
+                double tab[kExnerTabDoubles];
+                build_exner_table(tab);
+                void *d = nullptr;
+                if (hipMalloc(&d, sizeof tab) != hipSuccess ||
+                    hipMemcpy(d, tab, sizeof tab, hipMemcpyHostToDevice) != hipSuccess)
+                    return bail(GCM_ERR_HIP, "gcm_create: exner table upload failed");
+                h->allocs.push_back(d);
+                h->exner_tab = (double *)d;
+            }
+            h->rows_per_band = sw2d_fused_rows_per_band(h->W, h->H, temp, h->has[GCM_Q] ? cfg->tracer : 0, h->wrap);
             break;
         }
         case GCM_PE25D: {
@@ -246,6 +263,7 @@ static Sw2dArgs base_args(gcm_handle *h, double dt) {
     a.bp = h->cur[GCM_P];
     a.bt = h->cur[GCM_T];
     a.bq = h->cur[GCM_Q];
+    a.exner_tab = h->exner_tab;
     a.W = h->W;
     a.H = h->H;
     a.wrap_j = h->wrap ? 1 : 0;
@@ -257,6 +275,8 @@ static Sw2dArgs base_args(gcm_handle *h, double dt) {
     a.inv_dx = 1.0 / h->cfg.dx;
     a.dx2 = h->cfg.dx * h->cfg.dx;
     a.inv_dx2 = 1.0 / (h->cfg.dx * h->cfg.dx);
+    a.h_dx = 0.5 / h->cfg.dx;
+    a.dtdx = dt / h->cfg.dx;
     return a;
 }
 

@@ -5,9 +5,9 @@
 
 namespace gcm {
 
+constexpr int kExnerTabDoubles = 256;  // [0,128): E_e, e = -64..63; then 64 x {rc_i, ck_i}
 constexpr int kGhost = 2;        // ghost rows on each side of a latitude band
 constexpr int kStripCols = 60;   // output columns per wave in the fused kernel (64 lanes - 2x2 halo)
-constexpr int kWavesPerBlock = 4;
 
 // Pointers address interior row 0; with wrap_j == 0 rows -2,-1 and H,H+1 are ghost rows.
 struct Sw2dArgs {
@@ -16,11 +16,14 @@ struct Sw2dArgs {
     const double *sgeo, *sirho, *sst;       // staged TEMP: derived fields of the stage state
     double *ou, *ov, *op, *ot, *oq;         // output
     double *dgeo, *dirho, *dst;             // derive kernel outputs
+    const double *exner_tab;                // device copy of the 256-double exner table
     int W, H;                               // columns, rows owned
     int wrap_j;                             // 1: rows wrap modulo H (single band); 0: ghost rows
     int j0, j1;                             // row range [j0, j1) to produce
     int rows_per_band;                      // fused: output rows per wave
     double dt, dx, inv_dx, dx2, inv_dx2;
+    double h_dx;                            // 0.5 / dx (exact halving folded in)
+    double dtdx;                            // dt / dx
 };
 
 // staged variant
@@ -30,7 +33,10 @@ void launch_tracer_axis(const Sw2dArgs &a, int axis, bool limit, const double *q
                         double *q_out, hipStream_t s);
 // fused variant: predictor + corrector (+ both tracer passes) in one launch
 void launch_sw2d_fused(const Sw2dArgs &a, bool temp, int tracer, hipStream_t s);
-int sw2d_fused_rows_per_band(int W, int H);
+int sw2d_fused_rows_per_band(int W, int H, bool temp, int tracer, bool wrap);
+
+// fills tab[256] (host) for gcm_math.h's exner(); kappa and P0 as in constants.py:28,31
+void build_exner_table(double *tab);
 
 // ghost rows for a single band that is stepped with wrap_j == 0 (tests) and halo pack/unpack
 void launch_copy_rows(double *dst, const double *src, int W, int nrows, hipStream_t s);

@@ -12,6 +12,7 @@
 //           run in one launch, so every field is read once and written once per step.
 #include "sw2d_kernels.h"
 
+#include <cmath>
 #include <cstdlib>
 
 #include "gcm_math.h"
@@ -26,13 +27,27 @@ __device__ __forceinline__ long row_off(int j, int H, int W, bool wrap) {
     return (long)j * W;
 }
 
+void build_exner_table(double *tab) {
+    const long double kappa = (long double)kKappa, ln2 = logl(2.0L);
+    for (int e = -64; e <= 63; ++e)
+        tab[e + 64] = (double)expl(kappa * ((long double)e * ln2 - logl((long double)kP0)));
+    for (int i = 0; i < 64; ++i) {
+        const double rc = (double)(1.0L / (1.0L + ((long double)i + 0.5L) / 64.0L));
+        tab[128 + 2 * i] = rc;
+        tab[129 + 2 * i] = (double)powl(1.0L / (long double)rc, kappa);
+    }
+}
+
 // ------------------------------------------------------------------ staged
 __global__ __launch_bounds__(256) void sw2d_derive_kernel(Sw2dArgs a) {
+    __shared__ double tab[kExnerTabDoubles];
+    tab[threadIdx.y * 64 + threadIdx.x] = a.exner_tab[threadIdx.y * 64 + threadIdx.x];
+    __syncthreads();
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int j = a.j0 + blockIdx.y * 4 + threadIdx.y;
     if (i >= a.W || j >= a.j1) return;
     const long o = (long)j * a.W + i;
-    Thermo th = thermo(a.sp[o], a.st[o], a.dx2);
+    Thermo th = thermo(a.sp[o], a.st[o], a.dx2, tab);
     a.dgeo[o] = th.geo;
     a.dirho[o] = th.inv_rho;
     a.dst[o] = th.st;
@@ -60,14 +75,14 @@ __global__ __launch_bounds__(256) void sw2d_stage_kernel(Sw2dArgs a) {
         ge = a.sgeo[rc + ie];
         gs = a.sgeo[rs + i];
     }
-    double du = adv_vel_u(uc, uw, ue, un, us, vc, vw, vs, vsw, a.inv_dx) + geo_grad(ge, gc, a.inv_dx);
-    double dv = adv_vel_v(vc, vw, ve, vn, vs, uc, un, uw, usw, a.inv_dx) + geo_grad(gs, gc, a.inv_dx);
+    double du = adv_vel_u(uc, uw, ue, un, us, vc, vw, vs, vsw, a.h_dx) + geo_grad(ge, gc, a.inv_dx);
+    double dv = adv_vel_v(vc, vw, ve, vn, vs, uc, un, uw, usw, a.h_dx) + geo_grad(gs, gc, a.inv_dx);
     if (TEMP) {
         const double vis = visc_u(uc, uw, ue, un, us, a.inv_dx2) * a.sirho[rc + i];
         du -= vis;
         dv -= vis;  // the v equation uses the viscosity of u, matsumo_temp.py:75,91
     }
-    const double dp = adv_geo(uc, uw, vc, vn, pc, pw, pe, pn, ps, a.inv_dx);
+    const double dp = adv_geo(uc, uw, vc, vn, pc, pw, pe, pn, ps, a.h_dx);
     const long o = (long)j * W + i;
     const double bp = a.bp[o];
     const double pnew = bp - a.dt * dp;
@@ -76,7 +91,7 @@ __global__ __launch_bounds__(256) void sw2d_stage_kernel(Sw2dArgs a) {
     a.op[o] = pnew;
     if (TEMP) {
         const double dst = adv_geo(uc, uw, vc, vn, a.sst[rc + i], a.sst[rc + iw], a.sst[rc + ie],
-                                   a.sst[rn + i], a.sst[rs + i], a.inv_dx);
+                                   a.sst[rn + i], a.sst[rs + i], a.h_dx);
         const double tt = bp * a.bt[o] * a.dx2 - a.dt * dst;
         a.ot[o] = tt * rcp(pnew * a.dx2);  // unscaling, matsumo_temp.py:33-35
     }
@@ -99,16 +114,16 @@ __global__ __launch_bounds__(256) void tracer_axis_kernel(Sw2dArgs a, const doub
                    rm = row_off(j - 1, H, W, wrap), rmm = row_off(j - 2, H, W, wrap);
         const double qmm = qin[rmm + i], qm = qin[rm + i], q0 = qin[rc + i], q1 = qin[r1 + i],
                      q2 = qin[r2 + i];
-        f = face_flux<LIMIT>(a.bv[rc + i], qm, q0, q1, q2, a.dt, a.inv_dx);
-        fm = face_flux<LIMIT>(a.bv[rm + i], qmm, qm, q0, q1, a.dt, a.inv_dx);
+        f = face_flux<LIMIT>(a.bv[rc + i], qm, q0, q1, q2, a.dtdx);
+        fm = face_flux<LIMIT>(a.bv[rm + i], qmm, qm, q0, q1, a.dtdx);
         qout[(long)j * W + i] = q0 - f + fm;
     } else {
         auto wi = [W](int x) { x %= W; return x < 0 ? x + W : x; };
         const int i1 = wi(i + 1), i2 = wi(i + 2), im = wi(i - 1), imm = wi(i - 2);
         const double qmm = qin[rc + imm], qm = qin[rc + im], q0 = qin[rc + i], q1 = qin[rc + i1],
                      q2 = qin[rc + i2];
-        f = face_flux<LIMIT>(a.bu[rc + i], qm, q0, q1, q2, a.dt, a.inv_dx);
-        fm = face_flux<LIMIT>(a.bu[rc + im], qmm, qm, q0, q1, a.dt, a.inv_dx);
+        f = face_flux<LIMIT>(a.bu[rc + i], qm, q0, q1, q2, a.dtdx);
+        fm = face_flux<LIMIT>(a.bu[rc + im], qmm, qm, q0, q1, a.dtdx);
         qout[(long)j * W + i] = q0 - f + fm;
     }
 }
@@ -152,15 +167,15 @@ struct Row {
 };
 
 template <bool TEMP>
-__device__ __forceinline__ Row make_row(double u, double v, double p, double t, double dx2) {
-    Row r;
+__device__ __forceinline__ void make_row(Row &r, double u, double v, double p, double t,
+                                         double dx2, const double *tab) {
     r.u = u;
     r.v = v;
     r.p = p;
     r.uw = from_west(u);
     r.vw = from_west(v);
     if (TEMP) {
-        Thermo th = thermo(p, t, dx2);
+        Thermo th = thermo(p, t, dx2, tab);
         r.st = th.st;
         r.g = th.geo;
         r.irho = th.inv_rho;
@@ -169,7 +184,6 @@ __device__ __forceinline__ Row make_row(double u, double v, double p, double t, 
         r.g = p;
         r.irho = 0.0;
     }
-    return r;
 }
 
 struct Tend {
@@ -179,50 +193,43 @@ struct Tend {
 // tendencies at the centre row R0 of a 3-row window (north RM, south RP)
 template <bool TEMP>
 __device__ __forceinline__ Tend tendencies(const Row &RM, const Row &R0, const Row &RP,
-                                           double inv_dx, double inv_dx2) {
+                                           double inv_dx, double h_dx, double inv_dx2) {
     const double ue = from_east(R0.u), ve = from_east(R0.v);
     const double pw = from_west(R0.p), pe = from_east(R0.p);
     const double ge = TEMP ? from_east(R0.g) : pe;
     Tend t;
-    t.du = adv_vel_u(R0.u, R0.uw, ue, RM.u, RP.u, R0.v, R0.vw, RP.v, RP.vw, inv_dx) +
+    t.du = adv_vel_u(R0.u, R0.uw, ue, RM.u, RP.u, R0.v, R0.vw, RP.v, RP.vw, h_dx) +
            geo_grad(ge, R0.g, inv_dx);
-    t.dv = adv_vel_v(R0.v, R0.vw, ve, RM.v, RP.v, R0.u, RM.u, R0.uw, RP.uw, inv_dx) +
+    t.dv = adv_vel_v(R0.v, R0.vw, ve, RM.v, RP.v, R0.u, RM.u, R0.uw, RP.uw, h_dx) +
            geo_grad(RP.g, R0.g, inv_dx);
     if (TEMP) {
         const double vis = visc_u(R0.u, R0.uw, ue, RM.u, RP.u, inv_dx2) * R0.irho;
         t.du -= vis;
         t.dv -= vis;
     }
-    t.dp = adv_geo(R0.u, R0.uw, R0.v, RM.v, R0.p, pw, pe, RM.p, RP.p, inv_dx);
+    t.dp = adv_geo(R0.u, R0.uw, R0.v, RM.v, R0.p, pw, pe, RM.p, RP.p, h_dx);
     t.dst = 0.0;
     if (TEMP) {
         const double stw = from_west(R0.st), ste = from_east(R0.st);
-        t.dst = adv_geo(R0.u, R0.uw, R0.v, RM.v, R0.st, stw, ste, RM.st, RP.st, inv_dx);
+        t.dst = adv_geo(R0.u, R0.uw, R0.v, RM.v, R0.st, stw, ste, RM.st, RP.st, h_dx);
     }
     return t;
 }
 
-template <bool TEMP, int TRACER, bool WRAPJ>
-__global__ __launch_bounds__(256) void sw2d_fused_kernel(Sw2dArgs a) {
-    const int W = a.W, H = a.H;
-    const int lane = threadIdx.x & 63;
-    const int strip = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const int i0 = strip * kStripCols;
-    if (i0 >= W) return;  // wave-uniform; the kernel has no barriers
-    const int ja = a.j0 + blockIdx.y * a.rows_per_band;
-    const int jb = min(ja + a.rows_per_band, a.j1);
-    if (ja >= jb) return;
-    const int col = i0 - 2 + lane;
-    int ci = col % W;
-    if (ci < 0) ci += W;
-    const bool store_lane = lane >= 2 && lane < 62 && col < W;
-    const double dt = a.dt, inv_dx = a.inv_dx, inv_dx2 = a.inv_dx2, dx2 = a.dx2;
+struct Raw {
+    double u, v, p, t, q;
+};
 
-    struct Raw {
-        double u, v, p, t, q;
-    };
-    auto load = [&](int j) {
-        const long o = row_off(j, H, W, WRAPJ) + ci;
+template <bool TEMP, int TRACER, bool WRAPJ>
+struct FusedCtx {
+    const Sw2dArgs &a;
+    const double *tab;
+    int ci, col, ja, jb;
+    bool store_lane;
+    double f0_prev;
+
+    __device__ __forceinline__ Raw load(int j) const {
+        const long o = row_off(j, a.H, a.W, WRAPJ) + ci;
         Raw r;
         r.u = a.bu[o];
         r.v = a.bv[o];
@@ -230,42 +237,33 @@ __global__ __launch_bounds__(256) void sw2d_fused_kernel(Sw2dArgs a) {
         r.t = TEMP ? a.bt[o] : 0.0;
         r.q = TRACER ? a.bq[o] : 0.0;
         return r;
-    };
+    }
 
-    Raw x = load(ja - 2);
-    Row BM = make_row<TEMP>(x.u, x.v, x.p, x.t, dx2);
-    double qmm = 0.0, qm = x.q;
-    x = load(ja - 1);
-    Row B0 = make_row<TEMP>(x.u, x.v, x.p, x.t, dx2);
-    double q0 = x.q;
-    x = load(ja);
-    Row BP = make_row<TEMP>(x.u, x.v, x.p, x.t, dx2);
-    double qp = x.q;
-    Raw nxt = load(ja + 1);
-    Row SM, S0, SP;
-    SM = S0 = SP = BM;  // overwritten before first use
-    double f0_prev = 0.0;
-
-    for (int r = ja - 1; r <= jb; ++r) {
-        // ---- predictor: star row r from base rows r-1, r, r+1
+    // One row step.  On entry BM/B0/BP hold base rows r-1, r, r+1, SM/S0 the predicted rows
+    // r-2, r-1; SN is a dead slot that receives predicted row r.  On exit BM's slot holds
+    // base row r+2 (from the prefetched `nxt`) and `nxt` is row r+3: the caller rotates the
+    // slot names instead of moving registers.
+    __device__ __forceinline__ void iter(int r, Row &BM, Row &B0, Row &BP, Row &SN, Row &SM,
+                                         Row &S0, Raw &nxt, double &qmm, double &qm, double &q0,
+                                         double &qp) {
+        const double dt = a.dt, inv_dx = a.inv_dx, h_dx = a.h_dx, inv_dx2 = a.inv_dx2,
+                     dx2 = a.dx2;
+        // ---- predictor: predicted row r from base rows r-1, r, r+1
         {
-            const Tend t = tendencies<TEMP>(BM, B0, BP, inv_dx, inv_dx2);
+            const Tend t = tendencies<TEMP>(BM, B0, BP, inv_dx, h_dx, inv_dx2);
             const double us = B0.u - dt * t.du;
             const double vs = B0.v - dt * t.dv;
             const double ps = B0.p - dt * t.dp;
             double ts = 0.0;
             if (TEMP) ts = (B0.st - dt * t.dst) * rcp(ps * dx2);
-            SM = S0;
-            S0 = SP;
-            SP = make_row<TEMP>(us, vs, ps, ts, dx2);
+            make_row<TEMP>(SN, us, vs, ps, ts, dx2, tab);
         }
-        // ---- tracer, axis 0 flux through the face between rows r-1 and r
+        // ---- tracer, axis-0 flux through the face between rows r-1 and r
         double f0_cur = 0.0;
-        if (TRACER && r >= ja)
-            f0_cur = face_flux<TRACER == 2>(BM.v, qmm, qm, q0, qp, dt, inv_dx);
-        // ---- corrector: output row r-1 from star rows r-2, r-1, r and base row r-1
+        if (TRACER && r >= ja) f0_cur = face_flux<TRACER == 2>(BM.v, qmm, qm, q0, qp, a.dtdx);
+        // ---- corrector: output row r-1 from predicted rows r-2, r-1, r and base row r-1
         if (r >= ja + 1) {
-            const Tend t = tendencies<TEMP>(SM, S0, SP, inv_dx, inv_dx2);
+            const Tend t = tendencies<TEMP>(SM, S0, SN, inv_dx, h_dx, inv_dx2);
             const double un = BM.u - dt * t.du;
             const double vn = BM.v - dt * t.dv;
             const double pn = BM.p - dt * t.dp;
@@ -275,11 +273,11 @@ __global__ __launch_bounds__(256) void sw2d_fused_kernel(Sw2dArgs a) {
                 const double qs = qm - f0_cur + f0_prev;  // after the axis-0 pass
                 const double qs_w = from_west(qs), qs_e = from_east(qs);
                 const double qs_ee = from_east(qs_e);
-                const double f1 = face_flux<TRACER == 2>(BM.u, qs_w, qs, qs_e, qs_ee, dt, inv_dx);
+                const double f1 = face_flux<TRACER == 2>(BM.u, qs_w, qs, qs_e, qs_ee, a.dtdx);
                 qn = qs - f1 + from_west(f1);
             }
             if (store_lane) {
-                const long o = (long)(r - 1) * W + col;
+                const long o = (long)(r - 1) * a.W + col;
                 a.ou[o] = un;
                 a.ov[o] = vn;
                 a.op[o] = pn;
@@ -287,49 +285,113 @@ __global__ __launch_bounds__(256) void sw2d_fused_kernel(Sw2dArgs a) {
                 if (TRACER) a.oq[o] = qn;
             }
         }
-        // ---- slide the windows one row south
+        // ---- slide south: the oldest base slot takes row r+2, prefetch row r+3
         f0_prev = f0_cur;
-        BM = B0;
-        B0 = BP;
-        BP = make_row<TEMP>(nxt.u, nxt.v, nxt.p, nxt.t, dx2);
-        qmm = qm;
-        qm = q0;
-        q0 = qp;
-        qp = nxt.q;
+        make_row<TEMP>(BM, nxt.u, nxt.v, nxt.p, nxt.t, dx2, tab);
+        if (TRACER) {
+            qmm = qm;
+            qm = q0;
+            q0 = qp;
+            qp = nxt.q;
+        }
         if (r + 3 <= jb + 1) nxt = load(r + 3);
+    }
+};
+
+template <bool TEMP, int TRACER, bool WRAPJ>
+__global__ __launch_bounds__(64) void sw2d_fused_kernel(Sw2dArgs a) {
+    const int W = a.W;
+    const int lane = threadIdx.x;
+    const int i0 = blockIdx.x * kStripCols;
+    __shared__ double tab[kExnerTabDoubles];
+    if (TEMP) {
+        for (int k = 0; k < kExnerTabDoubles / 64; ++k) tab[lane + 64 * k] = a.exner_tab[lane + 64 * k];
+        __syncthreads();
+    }
+    FusedCtx<TEMP, TRACER, WRAPJ> c{a, tab};
+    c.ja = a.j0 + blockIdx.y * a.rows_per_band;
+    c.jb = min(c.ja + a.rows_per_band, a.j1);
+    if (c.ja >= c.jb) return;
+    c.col = i0 - 2 + lane;
+    c.ci = c.col % W;
+    if (c.ci < 0) c.ci += W;
+    c.store_lane = lane >= 2 && lane < 62 && c.col < W;
+    c.f0_prev = 0.0;
+    const int ja = c.ja, jb = c.jb;
+
+    Row A, B, C, X, Y, Z;
+    Raw x = c.load(ja - 2);
+    make_row<TEMP>(A, x.u, x.v, x.p, x.t, a.dx2, tab);
+    double qmm = 0.0, qm = x.q;
+    x = c.load(ja - 1);
+    make_row<TEMP>(B, x.u, x.v, x.p, x.t, a.dx2, tab);
+    double q0 = x.q;
+    x = c.load(ja);
+    make_row<TEMP>(C, x.u, x.v, x.p, x.t, a.dx2, tab);
+    double qp = x.q;
+    Raw nxt = c.load(ja + 1);
+    X = Y = Z = A;  // overwritten before first use
+
+    // rows r = ja-1 .. jb, three per trip so that the window slots rotate by name
+    for (int r = ja - 1; r <= jb; r += 3) {
+        c.iter(r, A, B, C, X, Y, Z, nxt, qmm, qm, q0, qp);
+        if (r + 1 > jb) break;
+        c.iter(r + 1, B, C, A, Y, Z, X, nxt, qmm, qm, q0, qp);
+        if (r + 2 > jb) break;
+        c.iter(r + 2, C, A, B, Z, X, Y, nxt, qmm, qm, q0, qp);
     }
 }
 
-int sw2d_fused_rows_per_band(int W, int H) {
+template <bool TEMP, int TRACER>
+static const void *fused_fn(bool wrap) {
+    return wrap ? (const void *)sw2d_fused_kernel<TEMP, TRACER, true>
+                : (const void *)sw2d_fused_kernel<TEMP, TRACER, false>;
+}
+
+static const void *fused_kernel_ptr(bool temp, int tracer, bool wrap) {
+    if (!temp) return fused_fn<false, 0>(wrap);
+    if (tracer == 0) return fused_fn<true, 0>(wrap);
+    if (tracer == 1) return fused_fn<true, 1>(wrap);
+    return fused_fn<true, 2>(wrap);
+}
+
+// Rows per wave.  Large grids: one resident round -- as many waves as the chip holds at
+// this kernel's register footprint (a second, partly filled round would idle most SIMDs
+// at the tail); small grids: short bands so that every SIMD gets a wave.
+int sw2d_fused_rows_per_band(int W, int H, bool temp, int tracer, bool wrap) {
     if (const char *e = getenv("GCM_FUSED_ROWS")) {
         int v = atoi(e);
         if (v > 0) return v;
     }
-    const int strips = (W + kStripCols - 1) / kStripCols;
-    const int bands_wanted = (4096 + strips - 1) / strips;  // >= 16 waves per CU
-    int rpb = H / bands_wanted;
-    if (rpb < 8) rpb = 8;
-    if (rpb > 64) rpb = 64;
-    return rpb;
-}
-
-template <bool TEMP, int TRACER>
-static void launch_fused_t(const Sw2dArgs &a, dim3 g, hipStream_t s) {
-    if (a.wrap_j)
-        hipLaunchKernelGGL((sw2d_fused_kernel<TEMP, TRACER, true>), g, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((sw2d_fused_kernel<TEMP, TRACER, false>), g, dim3(256), 0, s, a);
+    int waves_per_cu = 12, cus = 256, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        cus = prop.multiProcessorCount;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fused_kernel_ptr(temp, tracer, wrap), 64,
+                                                     0) == hipSuccess && nb > 0)
+        waves_per_cu = nb;
+    const long slots = (long)waves_per_cu * cus;
+    const long strips = (W + kStripCols - 1) / kStripCols;
+    auto waves = [&](int rpb) { return strips * ((H + rpb - 1) / rpb); };
+    if (waves(8) < slots) {  // small grid: aim at one wave per SIMD at least
+        long rpb = (long)H * strips / (4L * cus);
+        return (int)(rpb < 2 ? 2 : rpb > 8 ? 8 : rpb);
+    }
+    long rounds = (waves(64) + slots - 1) / slots;
+    long bands = rounds * slots / strips;  // floor: stay within `rounds` full rounds
+    if (bands < 1) bands = 1;
+    long rpb = (H + bands - 1) / bands;
+    return (int)(rpb < 8 ? 8 : rpb);
 }
 
 void launch_sw2d_fused(const Sw2dArgs &a, bool temp, int tracer, hipStream_t s) {
     if (a.j1 <= a.j0) return;
     const int strips = (a.W + kStripCols - 1) / kStripCols;
-    dim3 g((strips + kWavesPerBlock - 1) / kWavesPerBlock,
-           (a.j1 - a.j0 + a.rows_per_band - 1) / a.rows_per_band);
-    if (!temp) launch_fused_t<false, 0>(a, g, s);
-    else if (tracer == 0) launch_fused_t<true, 0>(a, g, s);
-    else if (tracer == 1) launch_fused_t<true, 1>(a, g, s);
-    else launch_fused_t<true, 2>(a, g, s);
+    dim3 g(strips, (a.j1 - a.j0 + a.rows_per_band - 1) / a.rows_per_band);
+    Sw2dArgs arg = a;
+    void *params[] = {&arg};
+    (void)hipLaunchKernel(fused_kernel_ptr(temp, tracer, a.wrap_j != 0), g, dim3(64), params, 0, s);
 }
 
 __global__ void copy_rows_kernel(double *dst, const double *src, long n) {

@@ -106,6 +106,9 @@ typedef struct {
 int gcm_abi_version(void);
 int gcm_device_count(void);                 /* gfx950 devices visible; 0 on a CPU-only box */
 const char *gcm_build_info(void);           /* compiler, offload arch, build flags          */
+/* The 256-double table the kernels use for (p/P0)**kappa (temperature.py:7-19): lets a host
+ * test check the device algorithm's accuracy without a GPU.  Returns 0. */
+int gcm_exner_table(double *out256);
 
 /* Lifetime.  Device buffers are library-owned inside the handle. */
 int gcm_create(const gcm_config *cfg, gcm_handle **out);
