@@ -159,11 +159,10 @@ void launch_tracer_axis(const Sw2dArgs &a, int axis, bool limit, const double *q
 }
 
 // ------------------------------------------------------------------ fused
-// One row of a state (base or predicted) as a lane keeps it: own column plus the
-// west neighbour of u and v (needed while the row is the window's south or centre
-// row) and, for TEMP, the derived fields.
+// One row of a state (base or predicted) as a lane keeps it: own column and, for TEMP,
+// the derived fields.
 struct Row {
-    double u, uw, v, vw, p, st, g, irho;
+    double u, v, p, st, g, irho;
 };
 
 template <bool TEMP>
@@ -172,8 +171,6 @@ __device__ __forceinline__ void make_row(Row &r, double u, double v, double p, d
     r.u = u;
     r.v = v;
     r.p = p;
-    r.uw = from_west(u);
-    r.vw = from_west(v);
     if (TEMP) {
         Thermo th = thermo(p, t, dx2, tab);
         r.st = th.st;
@@ -194,24 +191,27 @@ struct Tend {
 template <bool TEMP>
 __device__ __forceinline__ Tend tendencies(const Row &RM, const Row &R0, const Row &RP,
                                            double inv_dx, double h_dx, double inv_dx2) {
+    // i-1 / i+1 neighbours by DPP at the point of use (cheaper than carrying them in VGPRs)
     const double ue = from_east(R0.u), ve = from_east(R0.v);
+    const double uw = from_west(R0.u), vw = from_west(R0.v);
+    const double usw = from_west(RP.u), vsw = from_west(RP.v);
     const double pw = from_west(R0.p), pe = from_east(R0.p);
     const double ge = TEMP ? from_east(R0.g) : pe;
     Tend t;
-    t.du = adv_vel_u(R0.u, R0.uw, ue, RM.u, RP.u, R0.v, R0.vw, RP.v, RP.vw, h_dx) +
+    t.du = adv_vel_u(R0.u, uw, ue, RM.u, RP.u, R0.v, vw, RP.v, vsw, h_dx) +
            geo_grad(ge, R0.g, inv_dx);
-    t.dv = adv_vel_v(R0.v, R0.vw, ve, RM.v, RP.v, R0.u, RM.u, R0.uw, RP.uw, h_dx) +
+    t.dv = adv_vel_v(R0.v, vw, ve, RM.v, RP.v, R0.u, RM.u, uw, usw, h_dx) +
            geo_grad(RP.g, R0.g, inv_dx);
     if (TEMP) {
-        const double vis = visc_u(R0.u, R0.uw, ue, RM.u, RP.u, inv_dx2) * R0.irho;
+        const double vis = visc_u(R0.u, uw, ue, RM.u, RP.u, inv_dx2) * R0.irho;
         t.du -= vis;
         t.dv -= vis;
     }
-    t.dp = adv_geo(R0.u, R0.uw, R0.v, RM.v, R0.p, pw, pe, RM.p, RP.p, h_dx);
+    t.dp = adv_geo(R0.u, uw, R0.v, RM.v, R0.p, pw, pe, RM.p, RP.p, h_dx);
     t.dst = 0.0;
     if (TEMP) {
         const double stw = from_west(R0.st), ste = from_east(R0.st);
-        t.dst = adv_geo(R0.u, R0.uw, R0.v, RM.v, R0.st, stw, ste, RM.st, RP.st, h_dx);
+        t.dst = adv_geo(R0.u, uw, R0.v, RM.v, R0.st, stw, ste, RM.st, RP.st, h_dx);
     }
     return t;
 }
@@ -302,16 +302,24 @@ template <bool TEMP, int TRACER, bool WRAPJ>
 __global__ __launch_bounds__(64) void sw2d_fused_kernel(Sw2dArgs a) {
     const int W = a.W;
     const int lane = threadIdx.x;
-    const int i0 = blockIdx.x * kStripCols;
+    // Tile = (strip, band).  Workgroups are dealt round-robin over the 8 XCDs (b % 8 names the
+    // XCD group), each with its own L2: give every XCD a contiguous run of tiles, so that
+    // neighbouring strips -- which share halo columns and the 128-B lines straddling a strip
+    // edge that both write -- meet in one L2.  Speed only: any placement is correct.
+    const int strips = (W + kStripCols - 1) / kStripCols;
+    const int per_xcd = gridDim.x / 8;
+    const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const int band = tile / strips;
+    const int i0 = (tile - band * strips) * kStripCols;
     __shared__ double tab[kExnerTabDoubles];
     if (TEMP) {
         for (int k = 0; k < kExnerTabDoubles / 64; ++k) tab[lane + 64 * k] = a.exner_tab[lane + 64 * k];
         __syncthreads();
     }
     FusedCtx<TEMP, TRACER, WRAPJ> c{a, tab};
-    c.ja = a.j0 + blockIdx.y * a.rows_per_band;
+    c.ja = a.j0 + band * a.rows_per_band;
     c.jb = min(c.ja + a.rows_per_band, a.j1);
-    if (c.ja >= c.jb) return;
+    if (c.ja >= c.jb) return;   // also the padding tiles beyond the last band
     c.col = i0 - 2 + lane;
     c.ci = c.col % W;
     if (c.ci < 0) c.ci += W;
@@ -388,7 +396,8 @@ int sw2d_fused_rows_per_band(int W, int H, bool temp, int tracer, bool wrap) {
 void launch_sw2d_fused(const Sw2dArgs &a, bool temp, int tracer, hipStream_t s) {
     if (a.j1 <= a.j0) return;
     const int strips = (a.W + kStripCols - 1) / kStripCols;
-    dim3 g(strips, (a.j1 - a.j0 + a.rows_per_band - 1) / a.rows_per_band);
+    const int bands = (a.j1 - a.j0 + a.rows_per_band - 1) / a.rows_per_band;
+    dim3 g((unsigned)(((long)strips * bands + 7) / 8 * 8));  // 1-D, padded to 8 XCD groups
     Sw2dArgs arg = a;
     void *params[] = {&arg};
     (void)hipLaunchKernel(fused_kernel_ptr(temp, tracer, a.wrap_j != 0), g, dim3(64), params, 0, s);

@@ -4,7 +4,7 @@
 set -u
 TAG=$1; shift
 OUT=/root/repo/gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 /root/repo/bench.py --no-cpu "$@" > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 /root/repo/bench.py --no-cpu "$@" > /dev/null 2> $OUT/pmc_fetch.err
