@@ -78,10 +78,7 @@ class Core:
             cfg.dx_j, cfg.dx_h = tab(geom.dx_j, gh), tab(geom.dx_h, gh)
             cfg.sig, cfg.dsig = tab(geom.sig, self.L), tab(geom.dsig, self.L)
             cfg.sigb, cfg.sigt = tab(geom.sigb, self.L), tab(geom.sigt, self.L)
-            hm = np.asarray(geom.heightmap, dtype=np.float64)
-            if hm.shape == (gh, self.W):
-                hm = hm[row0:row0 + self.H]
-            cfg.heightmap = tab(hm, self.H * self.W)
+            cfg.heightmap = tab(geom.heightmap, gh * self.W)
         self._h = _lib._H()
         rc = lib.gcm_create(C.byref(cfg), C.byref(self._h))
         if rc != _lib.OK:

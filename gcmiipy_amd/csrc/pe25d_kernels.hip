@@ -1,15 +1,774 @@
+// GCM_PE25D: 2.5-D sigma-level primitive equations, Matsuno on the lat-lon C-grid
+// (reference dynamics.py:15-237, low_pass.py:41-78, temperature.py:7-19).
+//
+// Device layout: 3-D fields are [j][k][i] (i fastest, then the L levels, then the rows), so a
+// latitude band and its ghost rows are contiguous slabs; p is [j][i].  The host-facing layout
+// stays the reference's [k][j][i]; set/get transpose on the device.
+//
+// One half_timestep (dynamics.py:183-227) is four launches:
+//   K1 spu_filter   spu = arakawa_1977(su * iph(sp))            one workgroup per (row, level pair)
+//   K2 column       conv, pit, sigma-dot, p_n; rho, phi          one thread per (j, i) column
+//   K3 pgf_filter   pgfu = arakawa_1977(pgu + phiu)              one workgroup per (row, level pair)
+//   K4 update       advec_m_pu, advec_sig, advec_t, un_pu/un_pv  one thread per cell
+// The zonal filter is a complex Stockham FFT in LDS: two levels of one row are packed as
+// real and imaginary part (the filter multiplier is real and symmetric in the wavenumber, so
+// it acts on both parts independently), multiplied by S[j][n] and transformed back.
 #include "pe25d_kernels.h"
+
+#include <cmath>
+#include <cstring>
+
+#include "gcm_math.h"
+
 namespace gcm {
-struct Pe25d {};
-Pe25d *pe25d_create(const gcm_config &, hipStream_t, std::string *err) { *err = "GCM_PE25D not built yet"; return nullptr; }
-void pe25d_destroy(Pe25d *) {}
-int pe25d_set(Pe25d *, bool, const double *, const double *, const double *, const double *, const double *, std::string *) { return GCM_ERR_UNSUPPORTED; }
-int pe25d_get(Pe25d *, bool, double *, double *, double *, double *, double *, std::string *) { return GCM_ERR_UNSUPPORTED; }
-int pe25d_step(Pe25d *, double, hipStream_t, std::string *) { return GCM_ERR_UNSUPPORTED; }
-int pe25d_step_part(Pe25d *, int, double, hipStream_t, std::string *) { return GCM_ERR_UNSUPPORTED; }
-int pe25d_half(Pe25d *, int, double, hipStream_t, std::string *) { return GCM_ERR_UNSUPPORTED; }
-size_t pe25d_halo_bytes(const Pe25d *) { return 0; }
-int pe25d_halo(Pe25d *, bool, int, void *, hipStream_t, std::string *) { return GCM_ERR_UNSUPPORTED; }
-const double *pe25d_field(Pe25d *, int, long *n) { *n = 0; return nullptr; }
-void pe25d_timing(Pe25d *, std::vector<hipEvent_t> *, size_t *) {}
+
+constexpr int kMaxRadices = 24;
+
+struct FftPlan {
+    int n, nrad;
+    int rad[kMaxRadices];
+};
+
+struct PeArgs {
+    // base (time n) and stage state, device layout, pointers at interior row 0
+    const double *p, *u, *v, *t, *q;
+    const double *sp, *su, *sv, *st, *sq;
+    double *op, *ou, *ov, *ot, *oq;
+    // intermediates
+    double *spu, *sd, *phi, *rho, *pgfu;   // 3-D
+    double *pit, *pn;                      // 2-D
+    // tables (device)
+    const double *inv_dxj, *inv_dxh;       // [Hg] reciprocals of geometry.py:136-137
+    const double *sig, *dsig, *inv_dsig, *sigb, *sigt;  // [L]
+    const double *heightmap;               // [Hg][W] (global rows) or null
+    const double *smul;                    // [Hg][W/2+1] filter multiplier (low_pass.py:61-72)
+    const double2 *tw;                     // [W] exp(-2 pi i n / W)
+    const double *exner_tab;
+    FftPlan plan;
+    int W, H, L, Hg, row0;                 // local rows, global rows, first global row
+    int wrap;                              // 1: rows wrap modulo H (single band)
+    int filter;
+    int j0, j1;                            // rows to produce
+    double dt, inv_dy, ptop;
+};
+
+__device__ __forceinline__ int wrapi(int x, int n) {
+    x %= n;
+    return x < 0 ? x + n : x;
 }
+
+struct Idx {
+    int W, H, L, wrap;
+    __device__ __forceinline__ int jr(int j) const { return wrap ? wrapi(j, H) : j; }
+    __device__ __forceinline__ long r3(int j) const { return (long)jr(j) * L * W; }   // row slab
+    __device__ __forceinline__ long r2(int j) const { return (long)jr(j) * W; }
+};
+
+// ---------------------------------------------------------------- FFT in LDS
+// Stockham autosort, mixed radix.  x -> result returned in x or y (pointer returned).
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+template <bool INV>
+__device__ double2 *fft_lds(double2 *x, double2 *y, const double2 *tw, const FftPlan &P) {
+    const int N = P.n;
+    int Ns = 1;
+    for (int pass = 0; pass < P.nrad; ++pass) {
+        const int r = P.rad[pass];
+        const int nb = N / r;
+        const int tstep = N / (Ns * r);  // twiddle index step
+        for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+            const int k = b % Ns;
+            const int j0 = (b / Ns) * Ns * r + k;
+            if (r == 2) {
+                double2 a0 = x[b], a1 = x[b + nb];
+                double2 w = tw[k * tstep];
+                if (INV) w.y = -w.y;
+                a1 = cmul(a1, w);
+                y[j0] = make_double2(a0.x + a1.x, a0.y + a1.y);
+                y[j0 + Ns] = make_double2(a0.x - a1.x, a0.y - a1.y);
+            } else if (r == 4) {
+                double2 a0 = x[b], a1 = x[b + nb], a2 = x[b + 2 * nb], a3 = x[b + 3 * nb];
+                double2 w1 = tw[k * tstep], w2 = tw[2 * k * tstep], w3 = tw[3 * k * tstep];
+                if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+                a1 = cmul(a1, w1);
+                a2 = cmul(a2, w2);
+                a3 = cmul(a3, w3);
+                const double2 s02 = make_double2(a0.x + a2.x, a0.y + a2.y);
+                const double2 d02 = make_double2(a0.x - a2.x, a0.y - a2.y);
+                const double2 s13 = make_double2(a1.x + a3.x, a1.y + a3.y);
+                const double2 d13 = make_double2(a1.x - a3.x, a1.y - a3.y);
+                // forward: -i * d13 = (d13.y, -d13.x); inverse: +i * d13 = (-d13.y, d13.x)
+                const double2 jd = INV ? make_double2(-d13.y, d13.x) : make_double2(d13.y, -d13.x);
+                y[j0] = make_double2(s02.x + s13.x, s02.y + s13.y);
+                y[j0 + Ns] = make_double2(d02.x + jd.x, d02.y + jd.y);
+                y[j0 + 2 * Ns] = make_double2(s02.x - s13.x, s02.y - s13.y);
+                y[j0 + 3 * Ns] = make_double2(d02.x - jd.x, d02.y - jd.y);
+            } else {
+                // generic radix: out[q] = sum_m (x_m w^(m k)) W_r^(q m), W_r^t = tw[(t mod r) N/r]
+                const int rstep = N / r;
+                for (int qq = 0; qq < r; ++qq) {
+                    double2 acc = make_double2(0.0, 0.0);
+                    for (int m = 0; m < r; ++m) {
+                        double2 w = tw[(m * k * tstep + ((qq * m) % r) * rstep) % N];
+                        if (INV) w.y = -w.y;
+                        const double2 t = cmul(x[b + m * nb], w);
+                        acc.x += t.x;
+                        acc.y += t.y;
+                    }
+                    y[j0 + qq * Ns] = acc;
+                }
+            }
+        }
+        __syncthreads();
+        double2 *tmp = x;
+        x = y;
+        y = tmp;
+        Ns *= r;
+    }
+    return x;
+}
+
+// filter two real rows held as re/im of x[0..N): FFT, multiply by S[n] (n folded), inverse FFT.
+// Returns the buffer holding the result (already scaled by 1/N).
+__device__ double2 *filter_rows(double2 *x, double2 *y, const PeArgs &a, int jglob) {
+    const int N = a.W;
+    double2 *z = fft_lds<false>(x, y, a.tw, a.plan);
+    const double *S = a.smul + (long)jglob * (N / 2 + 1);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const double s = S[n <= N / 2 ? n : N - n];
+        z[n].x *= s;
+        z[n].y *= s;
+    }
+    __syncthreads();
+    double2 *o = (z == x) ? y : x;
+    double2 *res = fft_lds<true>(z, o, a.tw, a.plan);
+    const double inv_n = 1.0 / (double)N;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        res[n].x *= inv_n;
+        res[n].y *= inv_n;
+    }
+    __syncthreads();
+    return res;
+}
+
+// ---------------------------------------------------------------- K1: spu = filter(su * iph(sp))
+__global__ __launch_bounds__(256) void pe_spu_filter_kernel(PeArgs a) {
+    extern __shared__ double2 lds[];
+    double2 *x = lds, *y = lds + a.W;
+    const Idx ix{a.W, a.H, a.L, a.wrap};
+    const int j = a.j0 + blockIdx.x;
+    const int k0 = 2 * blockIdx.y, k1 = k0 + 1;
+    const bool two = k1 < a.L;
+    const int W = a.W;
+    const double *sp = a.sp + ix.r2(j);
+    const double *su0 = a.su + ix.r3(j) + (long)k0 * W;
+    const double *su1 = su0 + W;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+        const int ie = i + 1 == W ? 0 : i + 1;
+        const double pe = (sp[i] + sp[ie]) * 0.5;      // iph(p), dynamics.py:15-17
+        x[i] = make_double2(su0[i] * pe, two ? su1[i] * pe : 0.0);
+    }
+    __syncthreads();
+    double2 *res = x;
+    if (a.filter && W > 1) res = filter_rows(x, y, a, wrapi(a.row0 + j, a.Hg));
+    double *o0 = a.spu + ix.r3(j) + (long)k0 * W;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+        o0[i] = res[i].x;
+        if (two) o0[W + i] = res[i].y;
+    }
+}
+
+// ---------------------------------------------------------------- K2: column kernel
+__global__ __launch_bounds__(256) void pe_column_kernel(PeArgs a) {
+    __shared__ double tab[kExnerTabDoubles];
+    tab[threadIdx.x] = a.exner_tab[threadIdx.x];
+    __syncthreads();
+    const Idx ix{a.W, a.H, a.L, a.wrap};
+    const int W = a.W, L = a.L;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j = a.j0 + blockIdx.y;
+    if (i >= W) return;
+    const int iw = i == 0 ? W - 1 : i - 1;
+    const int jg = wrapi(a.row0 + j, a.Hg);
+    const double inv_dxj = a.inv_dxj[jg], inv_dy = a.inv_dy;
+    const double spc = a.sp[ix.r2(j) + i], spn = a.sp[ix.r2(j - 1) + i], sps = a.sp[ix.r2(j + 1) + i];
+    const double jph_c = (spc + sps) * 0.5, jph_n = (spn + spc) * 0.5;  // jph(sp) at j, j-1
+    const long c3 = ix.r3(j), n3 = ix.r3(j - 1);
+    // ---- aflux, dynamics.py:35-46
+    double pit = 0.0;
+    for (int k = 0; k < L; ++k) {
+        const long o = c3 + (long)k * W;
+        const double spv_c = a.sv[o + i] * jph_c;
+        const double spv_n = a.sv[n3 + (long)k * W + i] * jph_n;
+        const double conv = ((a.spu[o + i] - a.spu[o + iw]) * inv_dxj + (spv_c - spv_n) * inv_dy) * a.dsig[k];
+        pit += conv;             // np.sum over k, ascending
+        a.sd[o + i] = conv;      // parked; turned into sigma-dot below
+    }
+    a.pit[ix.r2(j) + i] = pit;
+    a.pn[ix.r2(j) + i] = a.p[ix.r2(j) + i] - pit * a.dt;   // p_n = p - pit dt, dynamics.py:194
+    double rc = 0.0;
+    for (int k = L - 1; k >= 1; --k) {                       // cumsum(conv[::-1])[::-1]
+        const long o = c3 + (long)k * W + i;
+        rc += a.sd[o];
+        a.sd[o] = rc - pit * a.sigb[k];
+    }
+    a.sd[c3 + i] = 0.0;                                      // sd[0] = 0, dynamics.py:44
+    // ---- compute_geopotential, dynamics.py:111-143
+    const double hmG = a.heightmap ? a.heightmap[(long)jg * W + i] * kG : 0.0 * kG;
+    double t0 = 0.0, ex0 = 0.0;                              // level 0, for the k wrap at the top
+    double t_k = a.st[c3 + i];
+    double ex_k = exner(spc * a.sig[0] + a.ptop, tab);
+    t0 = t_k;
+    ex0 = ex_k;
+    double acc = 0.0;
+    for (int k = 0; k < L; ++k) {
+        const long o = c3 + (long)k * W + i;
+        const double tp = spc * a.sig[k] + a.ptop;
+        double t_n, ex_n;
+        if (k + 1 < L) {
+            t_n = a.st[o + W];
+            ex_n = exner(spc * a.sig[k + 1] + a.ptop, tab);
+        } else {
+            t_n = t0;            // kp() wraps to the bottom layer, coordinates_3d.py:55-56
+            ex_n = ex0;
+        }
+        const double tt = t_k * ex_k;                        // t / (P0/tp)**kappa
+        const double rho = tp * rcp(kRd * tt);
+        a.rho[o] = rho;
+        const double s1 = (a.sig[k] * spc * rcp(rho)) * a.dsig[k];
+        const double stp = kCp * ((t_k + t_n) * 0.5) * (ex_k - ex_n);
+        const double s2 = a.sigt[k] * stp;
+        acc += s1 - s2;
+        a.phi[o] = stp;          // parked
+        t_k = t_n;
+        ex_k = ex_n;
+    }
+    double run = acc + hmG;                                  // stp_n[0], dynamics.py:132
+    double prev = a.phi[c3 + i];
+    a.phi[c3 + i] = run;
+    for (int k = 1; k < L; ++k) {                            // phi = cumsum(stp_n)
+        const long o = c3 + (long)k * W + i;
+        const double cur = a.phi[o];
+        run += prev;
+        a.phi[o] = run;
+        prev = cur;
+    }
+}
+
+// ---------------------------------------------------------------- K3: pgfu = filter(pgu + phiu)
+__global__ __launch_bounds__(256) void pe_pgf_filter_kernel(PeArgs a) {
+    extern __shared__ double2 lds[];
+    double2 *x = lds, *y = lds + a.W;
+    const Idx ix{a.W, a.H, a.L, a.wrap};
+    const int j = a.j0 + blockIdx.x;
+    const int k0 = 2 * blockIdx.y, k1 = k0 + 1;
+    const bool two = k1 < a.L;
+    const int W = a.W;
+    const int jg = wrapi(a.row0 + j, a.Hg);
+    const double inv_dxj = a.inv_dxj[jg];
+    const double *sp = a.sp + ix.r2(j);
+    const long o0 = ix.r3(j) + (long)k0 * W, o1 = o0 + W;
+    const double sg0 = a.sig[k0], sg1 = two ? a.sig[k1] : 0.0;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+        const int ie = i + 1 == W ? 0 : i + 1;
+        const double pc = sp[i], pe = sp[ie];
+        const double iphp = (pc + pe) * 0.5;
+        const double gradp = (pe - pc) * inv_dxj;
+        double v[2] = {0.0, 0.0};
+        for (int s = 0; s < (two ? 2 : 1); ++s) {
+            const long o = s ? o1 : o0;
+            const double sg = s ? sg1 : sg0;
+            const double phiu = iphp * ((a.phi[o + ie] - a.phi[o + i]) * inv_dxj);      // dynamics.py:159
+            const double ppih = (sg * pc + sg * pe) * 0.5;
+            const double rhou = (a.rho[o + i] + a.rho[o + ie]) * 0.5;
+            const double pgu = ppih * rcp(rhou) * gradp;                                 // dynamics.py:162-165
+            v[s] = pgu + phiu;
+        }
+        x[i] = make_double2(v[0], v[1]);
+    }
+    __syncthreads();
+    double2 *res = x;
+    if (a.filter && W > 1) res = filter_rows(x, y, a, jg);
+    double *out = a.pgfu + o0;
+    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+        out[i] = res[i].x;
+        if (two) out[W + i] = res[i].y;
+    }
+}
+
+// ---------------------------------------------------------------- K4: update
+__global__ __launch_bounds__(256) void pe_update_kernel(PeArgs a) {
+    const Idx ix{a.W, a.H, a.L, a.wrap};
+    const int W = a.W, L = a.L;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    const int j = a.j0 + blockIdx.z;
+    if (i >= W) return;
+    const int iw = i == 0 ? W - 1 : i - 1, ie = i + 1 == W ? 0 : i + 1;
+    const int km = k == 0 ? L - 1 : k - 1, kp = k + 1 == L ? 0 : k + 1;
+    const int jg = wrapi(a.row0 + j, a.Hg);
+    const double inv_dxj = a.inv_dxj[jg], inv_dxh = a.inv_dxh[jg], inv_dy = a.inv_dy, dt = a.dt;
+    const long rc = ix.r3(j), rn = ix.r3(j - 1), rs = ix.r3(j + 1);
+    const long kc = (long)k * W, kmo = (long)km * W, kpo = (long)kp * W;
+    // surface pressure of the stage state on rows j-1 .. j+2
+    const double *spr = a.sp;
+    const long p_n = ix.r2(j - 1), p_c = ix.r2(j), p_s = ix.r2(j + 1), p_ss = ix.r2(j + 2);
+    const double sp_c = spr[p_c + i], sp_e = spr[p_c + ie];
+    const double sp_s = spr[p_s + i], sp_se = spr[p_s + ie], sp_ss = spr[p_ss + i];
+    const double sp_n = spr[p_n + i], sp_ne = spr[p_n + ie];
+    const double jph_c = (sp_c + sp_s) * 0.5, jph_ce = (sp_e + sp_se) * 0.5;     // jph(sp) at (j,i),(j,i+1)
+    const double jph_n = (sp_n + sp_c) * 0.5, jph_ne = (sp_ne + sp_e) * 0.5;     // at (j-1,i),(j-1,i+1)
+    const double jph_s = (sp_s + sp_ss) * 0.5;                                   // at (j+1,i)
+    // stage winds
+    const double su_c = a.su[rc + kc + i], su_w = a.su[rc + kc + iw], su_e = a.su[rc + kc + ie];
+    const double su_n = a.su[rn + kc + i], su_s = a.su[rs + kc + i];
+    const double sv_c = a.sv[rc + kc + i], sv_w = a.sv[rc + kc + iw], sv_e = a.sv[rc + kc + ie];
+    const double sv_n = a.sv[rn + kc + i], sv_ne = a.sv[rn + kc + ie], sv_s = a.sv[rs + kc + i];
+    // mass fluxes: spu filtered (K1); spv = sv * jph(sp), dynamics.py:20-22
+    const double spu_c = a.spu[rc + kc + i], spu_w = a.spu[rc + kc + iw], spu_e = a.spu[rc + kc + ie];
+    const double spu_s = a.spu[rs + kc + i], spu_sw = a.spu[rs + kc + iw];
+    const double spv_c = sv_c * jph_c, spv_e = sv_e * jph_ce;
+    const double spv_n = sv_n * jph_n, spv_ne = sv_ne * jph_ne;
+    const double spv_s = sv_s * jph_s;
+    // ---- advec_m_pu, dynamics.py:55-108
+    const double puum = ((su_c + su_w) * 0.5) * ((spu_c + spu_w) * 0.5);
+    const double puup = ((su_e + su_c) * 0.5) * ((spu_e + spu_c) * 0.5);
+    const double puvp = ((spv_c + spv_e) * 0.5) * ((su_c + su_s) * 0.5);
+    const double puvm = ((spv_n + spv_ne) * 0.5) * ((su_n + su_c) * 0.5);
+    const double pvvm = ((sv_c + sv_n) * 0.5) * ((spv_c + spv_n) * 0.5);
+    const double pvvp = ((sv_s + sv_c) * 0.5) * ((spv_s + spv_c) * 0.5);
+    const double pvup = ((sv_c + sv_e) * 0.5) * ((spu_c + spu_s) * 0.5);
+    const double pvum = ((sv_w + sv_c) * 0.5) * ((spu_w + spu_sw) * 0.5);
+    const double dut = (puum - puup) * inv_dxj + (puvm - puvp) * inv_dy + 0.0;
+    const double dvt = (pvvm - pvvp) * inv_dy + (pvum - pvup) * inv_dxh + 0.0;
+    // ---- pgf v-part, dynamics.py:160,167-169 (the u-part went through K3)
+    const double sg = a.sig[k];
+    const double phi_c = a.phi[rc + kc + i], phi_s = a.phi[rs + kc + i];
+    const double rho_c = a.rho[rc + kc + i], rho_s = a.rho[rs + kc + i];
+    const double phiv = jph_c * ((phi_s - phi_c) * inv_dy);
+    const double pgv = ((sg * sp_c + sg * sp_s) * 0.5) * rcp((rho_c + rho_s) * 0.5) * ((sp_s - sp_c) * inv_dy);
+    // ---- vertical advection, dynamics.py:49-52 with iph(sd), jph(sd), sd
+    const double sd_c = a.sd[rc + kc + i], sd_e = a.sd[rc + kc + ie], sd_s = a.sd[rs + kc + i];
+    const double sd_cp = a.sd[rc + kpo + i], sd_ep = a.sd[rc + kpo + ie], sd_sp = a.sd[rs + kpo + i];
+    const double inv_ds = a.inv_dsig[k];
+    const double su_m = a.su[rc + kmo + i], su_p = a.su[rc + kpo + i];
+    const double sv_m = a.sv[rc + kmo + i], sv_p = a.sv[rc + kpo + i];
+    const double st_c = a.st[rc + kc + i], st_m = a.st[rc + kmo + i], st_p = a.st[rc + kpo + i];
+    const double sq_c = a.sq[rc + kc + i], sq_m = a.sq[rc + kmo + i], sq_p = a.sq[rc + kpo + i];
+    const double sdi = (sd_c + sd_e) * 0.5, sdi_p = (sd_cp + sd_ep) * 0.5;
+    const double sdj = (sd_c + sd_s) * 0.5, sdj_p = (sd_cp + sd_sp) * 0.5;
+    const double dus = -((((su_c + su_m) * 0.5) * sdi - ((su_p + su_c) * 0.5) * sdi_p) * inv_ds);
+    const double dvs = -((((sv_c + sv_m) * 0.5) * sdj - ((sv_p + sv_c) * 0.5) * sdj_p) * inv_ds);
+    const double dts = -((((st_c + st_m) * 0.5) * sd_c - ((st_p + st_c) * 0.5) * sd_cp) * inv_ds);
+    const double dqs = -((((sq_c + sq_m) * 0.5) * sd_c - ((sq_p + sq_c) * 0.5) * sd_cp) * inv_ds);
+    // ---- momentum update, dynamics.py:186-212
+    const double pb_c = a.p[p_c + i], pb_e = a.p[p_c + ie], pb_s = a.p[p_s + i];
+    const double pu = a.u[rc + kc + i] * ((pb_c + pb_e) * 0.5);
+    const double pv = a.v[rc + kc + i] * ((pb_c + pb_s) * 0.5);
+    const double pgfu = a.pgfu[rc + kc + i];
+    const double pu_n = pu - (dut + dus + pgfu) * dt;
+    const double pv_n = pv - (dvt + dvs + phiv + pgv) * dt;
+    const double pn_c = a.pn[p_c + i], pn_e = a.pn[p_c + ie], pn_s = a.pn[p_s + i];
+    double u_n = pu_n * rcp((pn_c + pn_e) * 0.5);
+    double v_n = pv_n * rcp((pn_c + pn_s) * 0.5);
+    if (jg == a.Hg - 1) v_n *= 0.0;                          // v_n[:, -1, :] *= 0, dynamics.py:222
+    // ---- advec_t for t and q, dynamics.py:174-181,214-219
+    const double st_e = a.st[rc + kc + ie], st_w = a.st[rc + kc + iw];
+    const double st_s = a.st[rs + kc + i], st_n = a.st[rn + kc + i];
+    const double sq_e = a.sq[rc + kc + ie], sq_w = a.sq[rc + kc + iw];
+    const double sq_s = a.sq[rs + kc + i], sq_n = a.sq[rn + kc + i];
+    const double adt = (spu_c * ((st_c + st_e) * 0.5) - spu_w * ((st_w + st_c) * 0.5)) * inv_dxj +
+                       (spv_c * ((st_c + st_s) * 0.5) - spv_n * ((st_n + st_c) * 0.5)) * inv_dy;
+    const double adq = (spu_c * ((sq_c + sq_e) * 0.5) - spu_w * ((sq_w + sq_c) * 0.5)) * inv_dxj +
+                       (spv_c * ((sq_c + sq_s) * 0.5) - spv_n * ((sq_n + sq_c) * 0.5)) * inv_dy;
+    const double inv_pn = rcp(pn_c);
+    const double t_n = (a.t[rc + kc + i] * pb_c - (adt + dts) * dt) * inv_pn;
+    const double q_n = (a.q[rc + kc + i] * pb_c - (adq + dqs) * dt) * inv_pn;
+    const long o = (long)j * L * W + kc + i;                 // interior rows: no wrap needed
+    a.ou[o] = u_n;
+    a.ov[o] = v_n;
+    a.ot[o] = t_n;
+    a.oq[o] = q_n;
+    if (k == 0) a.op[(long)j * W + i] = pn_c;
+}
+
+// ---------------------------------------------------------------- layout transposes
+// host layout [k][j][i] (rows of THIS band only) <-> device [j][k][i]
+__global__ void pe_to_device_kernel(double *dst, const double *src, int W, int H, int L) {
+    const long n = (long)W * H * L;
+    for (long x = (long)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (long)gridDim.x * blockDim.x) {
+        const int i = x % W;
+        const long r = x / W;
+        const int k = r % L, j = r / L;
+        dst[x] = src[((long)k * H + j) * W + i];
+    }
+}
+__global__ void pe_to_host_kernel(double *dst, const double *src, int W, int H, int L) {
+    const long n = (long)W * H * L;
+    for (long x = (long)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (long)gridDim.x * blockDim.x) {
+        const int i = x % W;
+        const long r = x / W;
+        const int k = r % L, j = r / L;
+        dst[((long)k * H + j) * W + i] = src[x];
+    }
+}
+
+// ================================================================== host side
+struct Pe25d {
+    gcm_config cfg{};
+    int W = 0, H = 0, L = 0, Hg = 0;
+    bool wrap = true;
+    std::vector<void *> allocs;
+    // state sets: 0/1 ping-pong (cur = set[cur_i]), 2 = star.  [f] p,u,v,t,q; interior pointers
+    double *st[3][GCM_NFIELDS] = {};
+    int cur_i = 0;
+    bool star_valid = false;
+    double *spu = nullptr, *sd = nullptr, *phi = nullptr, *rho = nullptr, *pgfu = nullptr;
+    double *pit = nullptr, *pn = nullptr, *stage3 = nullptr;  // stage3: transpose staging
+    double *inv_dxj = nullptr, *inv_dxh = nullptr, *sig = nullptr, *dsig = nullptr,
+           *inv_dsig = nullptr, *sigb = nullptr, *sigt = nullptr, *heightmap = nullptr,
+           *smul = nullptr, *exner_tab = nullptr;
+    double2 *tw = nullptr;
+    FftPlan plan{};
+    std::vector<hipEvent_t> *ev = nullptr;
+    size_t *ev_used = nullptr;
+};
+
+static bool make_plan(int n, FftPlan *P) {
+    P->n = n;
+    P->nrad = 0;
+    int m = n;
+    auto push = [&](int r) { if (P->nrad < kMaxRadices) P->rad[P->nrad++] = r; };
+    while (m % 4 == 0) { push(4); m /= 4; }
+    while (m % 2 == 0) { push(2); m /= 2; }
+    for (int r = 3; r <= m && m > 1; r += 2)
+        while (m % r == 0) { push(r); m /= r; }
+    return m == 1 && P->nrad <= kMaxRadices;
+}
+
+template <typename T>
+static bool dev_upload(Pe25d *m, T **dst, const T *src, size_t count) {
+    void *d = nullptr;
+    if (hipMalloc(&d, count * sizeof(T)) != hipSuccess) return false;
+    m->allocs.push_back(d);
+    if (src && hipMemcpy(d, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return false;
+    if (!src && hipMemset(d, 0, count * sizeof(T)) != hipSuccess) return false;
+    *dst = (T *)d;
+    return true;
+}
+
+static size_t rows_alloc(const Pe25d *m) { return (size_t)m->H + 2 * kGhost; }
+
+Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
+    if (!cfg.dx_j || !cfg.dx_h || !cfg.sig || !cfg.dsig || !cfg.sigb || !cfg.sigt) {
+        *err = "GCM_PE25D: geometry tables (dx_j, dx_h, sig, dsig, sigb, sigt) are required";
+        return nullptr;
+    }
+    if (!(cfg.dy > 0)) { *err = "GCM_PE25D: dy must be > 0"; return nullptr; }
+    if (cfg.global_height < cfg.height || cfg.row0 < 0 || cfg.row0 + cfg.height > cfg.global_height) {
+        *err = "GCM_PE25D: band rows outside the global grid";
+        return nullptr;
+    }
+    if (cfg.nranks == 1 && cfg.global_height != cfg.height) {
+        *err = "GCM_PE25D: nranks == 1 needs height == global_height";
+        return nullptr;
+    }
+    if (cfg.filter && cfg.width > 1 && cfg.width % 2) {
+        *err = "GCM_PE25D: the zonal filter needs an even width (low_pass.py:57; numpy irfft)";
+        return nullptr;
+    }
+    Pe25d *m = new Pe25d;
+    m->cfg = cfg;
+    m->W = cfg.width;
+    m->H = cfg.height;
+    m->L = cfg.layers;
+    m->Hg = cfg.global_height;
+    m->wrap = cfg.nranks == 1;
+    const int W = m->W, L = m->L, Hg = m->Hg;
+    auto bad = [&](const char *what) {
+        *err = std::string("hip: GCM_PE25D allocation/upload failed: ") + what;
+        pe25d_destroy(m);
+        return (Pe25d *)nullptr;
+    };
+    if (W > 1 && (!make_plan(W, &m->plan) || (size_t)W * 32 > 160 * 1024)) {
+        *err = "GCM_PE25D: width not supported by the in-LDS FFT (too many factors or > 5120)";
+        pe25d_destroy(m);
+        return nullptr;
+    }
+    const size_t n2 = rows_alloc(m) * W, n3 = n2 * L;
+    for (int s = 0; s < 3; ++s)
+        for (int f = 0; f < GCM_NFIELDS; ++f) {
+            double *d = nullptr;
+            const size_t n = f == GCM_P ? n2 : n3;
+            if (!dev_upload<double>(m, &d, nullptr, n)) return bad("state");
+            m->st[s][f] = d + (size_t)kGhost * W * (f == GCM_P ? 1 : L);
+        }
+    double **inter3[] = {&m->spu, &m->sd, &m->phi, &m->rho, &m->pgfu};
+    for (double **pp : inter3) {
+        double *d = nullptr;
+        if (!dev_upload<double>(m, &d, nullptr, n3)) return bad("intermediate");
+        *pp = d + (size_t)kGhost * W * L;
+    }
+    double **inter2[] = {&m->pit, &m->pn};
+    for (double **pp : inter2) {
+        double *d = nullptr;
+        if (!dev_upload<double>(m, &d, nullptr, n2)) return bad("intermediate");
+        *pp = d + (size_t)kGhost * W;
+    }
+    if (!dev_upload<double>(m, &m->stage3, nullptr, (size_t)m->H * W * L)) return bad("staging");
+    // tables
+    std::vector<double> idj(Hg), idh(Hg), ids(L);
+    for (int j = 0; j < Hg; ++j) {
+        idj[j] = 1.0 / cfg.dx_j[j];
+        idh[j] = 1.0 / cfg.dx_h[j];
+    }
+    for (int k = 0; k < L; ++k) ids[k] = 1.0 / cfg.dsig[k];
+    if (!dev_upload(m, &m->inv_dxj, idj.data(), Hg) || !dev_upload(m, &m->inv_dxh, idh.data(), Hg) ||
+        !dev_upload(m, &m->sig, cfg.sig, L) || !dev_upload(m, &m->dsig, cfg.dsig, L) ||
+        !dev_upload(m, &m->inv_dsig, ids.data(), L) || !dev_upload(m, &m->sigb, cfg.sigb, L) ||
+        !dev_upload(m, &m->sigt, cfg.sigt, L))
+        return bad("tables");
+    if (cfg.heightmap && !dev_upload(m, &m->heightmap, cfg.heightmap, (size_t)Hg * W))
+        return bad("heightmap");
+    double tab[kExnerTabDoubles];
+    build_exner_table(tab);
+    if (!dev_upload(m, &m->exner_tab, tab, kExnerTabDoubles)) return bad("exner table");
+    const int lds_bytes = 2 * W * (int)sizeof(double2);
+    if (hipFuncSetAttribute((const void *)pe_spu_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void *)pe_pgf_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+        return bad("dynamic LDS size");
+    if (W > 1) {
+        // filter multiplier, low_pass.py:61-72, same expression order as the reference
+        const int nh = W / 2 + 1;
+        std::vector<double> S((size_t)Hg * nh);
+        for (int j = 0; j < Hg; ++j) {
+            const double drat = cfg.dy / cfg.dx_j[j];
+            S[(size_t)j * nh] = 1.0;
+            for (int n = 1; n < nh; ++n) {
+                const double bysn = 1.0 / std::sin(M_PI / W * (double)n);
+                const double sm = 1.0 - bysn / drat;
+                S[(size_t)j * nh + n] = 1.0 - std::fmax(sm, 0.0);
+            }
+        }
+        if (!dev_upload(m, &m->smul, S.data(), S.size())) return bad("filter multiplier");
+        std::vector<double2> tw(W);
+        for (int n = 0; n < W; ++n) {
+            const long double ang = -2.0L * 3.14159265358979323846264338327950288L * n / W;
+            tw[n] = make_double2((double)cosl(ang), (double)sinl(ang));
+        }
+        if (!dev_upload(m, &m->tw, tw.data(), W)) return bad("twiddles");
+    }
+    return m;
+}
+
+void pe25d_destroy(Pe25d *m) {
+    if (!m) return;
+    for (void *p : m->allocs) (void)hipFree(p);
+    delete m;
+}
+
+static int xfer(Pe25d *m, int set, bool to_dev, const double *const in[GCM_NFIELDS],
+                double *const out[GCM_NFIELDS], std::string *err) {
+    const int W = m->W, H = m->H, L = m->L;
+    const size_t b2 = sizeof(double) * (size_t)H * W, b3 = b2 * L;
+    for (int f = 0; f < GCM_NFIELDS; ++f) {
+        const void *hp = to_dev ? (const void *)in[f] : (const void *)out[f];
+        if (!hp) continue;
+        hipError_t e = hipSuccess;
+        if (f == GCM_P) {
+            e = to_dev ? hipMemcpy(m->st[set][f], in[f], b2, hipMemcpyHostToDevice)
+                       : hipMemcpy(out[f], m->st[set][f], b2, hipMemcpyDeviceToHost);
+        } else if (to_dev) {
+            e = hipMemcpy(m->stage3, in[f], b3, hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(pe_to_device_kernel, dim3(1024), dim3(256), 0, nullptr, m->st[set][f],
+                                   m->stage3, W, H, L);
+                e = hipDeviceSynchronize();
+            }
+        } else {
+            hipLaunchKernelGGL(pe_to_host_kernel, dim3(1024), dim3(256), 0, nullptr, m->stage3,
+                               m->st[set][f], W, H, L);
+            e = hipMemcpy(out[f], m->stage3, b3, hipMemcpyDeviceToHost);
+        }
+        if (e != hipSuccess) {
+            *err = std::string("pe25d state transfer: ") + hipGetErrorString(e);
+            return GCM_ERR_HIP;
+        }
+    }
+    return GCM_OK;
+}
+
+int pe25d_set(Pe25d *m, bool star, const double *p, const double *u, const double *v,
+              const double *t, const double *q, std::string *err) {
+    const double *in[GCM_NFIELDS] = {p, u, v, t, q};
+    (void)hipDeviceSynchronize();
+    int rc = xfer(m, star ? 2 : m->cur_i, true, in, nullptr, err);
+    if (rc == GCM_OK) m->star_valid = star;
+    return rc;
+}
+
+int pe25d_get(Pe25d *m, bool star, double *p, double *u, double *v, double *t, double *q,
+              std::string *err) {
+    if (star && !m->star_valid) {
+        *err = "get_star: no predicted state yet";
+        return GCM_ERR_STATE;
+    }
+    double *out[GCM_NFIELDS] = {p, u, v, t, q};
+    (void)hipDeviceSynchronize();
+    return xfer(m, star ? 2 : m->cur_i, false, nullptr, out, err);
+}
+
+static PeArgs make_args(Pe25d *m, int stage_set, int out_set, double dt) {
+    PeArgs a{};
+    double *const *B = m->st[m->cur_i];
+    double *const *S = m->st[stage_set];
+    double *const *O = m->st[out_set];
+    a.p = B[GCM_P]; a.u = B[GCM_U]; a.v = B[GCM_V]; a.t = B[GCM_T]; a.q = B[GCM_Q];
+    a.sp = S[GCM_P]; a.su = S[GCM_U]; a.sv = S[GCM_V]; a.st = S[GCM_T]; a.sq = S[GCM_Q];
+    a.op = O[GCM_P]; a.ou = O[GCM_U]; a.ov = O[GCM_V]; a.ot = O[GCM_T]; a.oq = O[GCM_Q];
+    a.spu = m->spu; a.sd = m->sd; a.phi = m->phi; a.rho = m->rho; a.pgfu = m->pgfu;
+    a.pit = m->pit; a.pn = m->pn;
+    a.inv_dxj = m->inv_dxj; a.inv_dxh = m->inv_dxh;
+    a.sig = m->sig; a.dsig = m->dsig; a.inv_dsig = m->inv_dsig; a.sigb = m->sigb; a.sigt = m->sigt;
+    a.heightmap = m->heightmap; a.smul = m->smul; a.tw = m->tw; a.exner_tab = m->exner_tab;
+    a.plan = m->plan;
+    a.W = m->W; a.H = m->H; a.L = m->L; a.Hg = m->Hg; a.row0 = m->cfg.row0;
+    a.wrap = m->wrap ? 1 : 0;
+    a.filter = m->cfg.filter;
+    a.dt = dt;
+    a.inv_dy = 1.0 / m->cfg.dy;
+    a.ptop = m->cfg.ptop;
+    return a;
+}
+
+static void tick(Pe25d *m, hipStream_t s) {
+    if (m->ev && m->ev_used && *m->ev_used < m->ev->size()) (void)hipEventRecord((*m->ev)[(*m->ev_used)++], s);
+}
+
+// one Euler stage over rows [j0, j1): state `stage_set` -> `out_set`, base = current
+static void half(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1, hipStream_t s) {
+    if (j1 <= j0) return;
+    PeArgs a = make_args(m, stage_set, out_set, dt);
+    const int W = m->W, L = m->L;
+    const int ext = m->wrap ? 0 : 1;             // intermediates are also needed on row j1 (south)
+    const size_t lds = (size_t)2 * W * sizeof(double2);
+    const int pairs = (L + 1) / 2;
+    a.j0 = j0;
+    a.j1 = j1 + ext;
+    hipLaunchKernelGGL(pe_spu_filter_kernel, dim3(a.j1 - a.j0, pairs), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(pe_column_kernel, dim3((W + 255) / 256, a.j1 - a.j0), dim3(256), 0, s, a);
+    a.j1 = j1;
+    hipLaunchKernelGGL(pe_pgf_filter_kernel, dim3(a.j1 - a.j0, pairs), dim3(256), lds, s, a);
+    tick(m, s);
+    hipLaunchKernelGGL(pe_update_kernel, dim3((W + 255) / 256, L, a.j1 - a.j0), dim3(256), 0, s, a);
+    tick(m, s);
+}
+
+int pe25d_half(Pe25d *m, int stage, double dt, hipStream_t s, std::string *err) {
+    if (!m->wrap) {
+        *err = "half_step on a latitude band: use step_part";
+        return GCM_ERR_UNSUPPORTED;
+    }
+    if (stage == 0) {
+        half(m, m->cur_i, 2, dt, 0, m->H, s);
+        m->star_valid = true;
+    } else {
+        if (!m->star_valid) {
+            *err = "half_step(1) before half_step(0)";
+            return GCM_ERR_STATE;
+        }
+        half(m, 2, 1 - m->cur_i, dt, 0, m->H, s);
+        m->cur_i = 1 - m->cur_i;
+        m->star_valid = false;
+    }
+    if (hipGetLastError() != hipSuccess) {
+        *err = "hip: pe25d kernel launch failed";
+        return GCM_ERR_HIP;
+    }
+    return GCM_OK;
+}
+
+int pe25d_step(Pe25d *m, double dt, hipStream_t s, std::string *err) {
+    if (!m->wrap) {
+        *err = "gcm_step: a latitude band needs ghost-row exchanges inside the step (use step_part)";
+        return GCM_ERR_STATE;
+    }
+    half(m, m->cur_i, 2, dt, 0, m->H, s);
+    half(m, 2, 1 - m->cur_i, dt, 0, m->H, s);
+    m->cur_i = 1 - m->cur_i;
+    m->star_valid = false;
+    if (hipGetLastError() != hipSuccess) {
+        *err = "hip: pe25d kernel launch failed";
+        return GCM_ERR_HIP;
+    }
+    return GCM_OK;
+}
+
+// Latitude band: part 0 = predictor (needs ghost rows of the current state),
+// part 1 = corrector (needs ghost rows of the predicted state), then the swap.
+int pe25d_step_part(Pe25d *m, int part, double dt, hipStream_t s, std::string *err) {
+    if (m->wrap) {
+        *err = "step_part: handle is not a latitude band";
+        return GCM_ERR_STATE;
+    }
+    if (part == 0) {
+        half(m, m->cur_i, 2, dt, 0, m->H, s);
+        m->star_valid = true;
+    } else {
+        half(m, 2, 1 - m->cur_i, dt, 0, m->H, s);
+        m->cur_i = 1 - m->cur_i;
+        m->star_valid = false;
+    }
+    if (hipGetLastError() != hipSuccess) {
+        *err = "hip: pe25d kernel launch failed";
+        return GCM_ERR_HIP;
+    }
+    return GCM_OK;
+}
+
+// ghost rows: [p: 2 rows][u,v,t,q: 2 rows x L levels]; contiguous in the device layout.
+// Which state is exchanged follows the step phase: the predicted state once it exists.
+size_t pe25d_halo_bytes(const Pe25d *m) {
+    return sizeof(double) * (size_t)kGhost * m->W * (1 + 4 * (size_t)m->L);
+}
+
+__global__ void pe_copy_kernel(double *dst, const double *src, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+int pe25d_halo(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s, std::string *err) {
+    const int set = m->star_valid ? 2 : m->cur_i;
+    double *b = (double *)dev_buf;
+    for (int f = 0; f < GCM_NFIELDS; ++f) {
+        const size_t per_row = (size_t)m->W * (f == GCM_P ? 1 : m->L);
+        const long n = (long)(kGhost * per_row);
+        double *base = m->st[set][f];
+        double *edge = side == 0 ? base : base + (size_t)(m->H - kGhost) * per_row;
+        double *ghost = side == 0 ? base - (size_t)kGhost * per_row : base + (size_t)m->H * per_row;
+        int blocks = (int)((n + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        if (pack) hipLaunchKernelGGL(pe_copy_kernel, dim3(blocks), dim3(256), 0, s, b, edge, n);
+        else hipLaunchKernelGGL(pe_copy_kernel, dim3(blocks), dim3(256), 0, s, ghost, b, n);
+        b += n;
+    }
+    if (hipGetLastError() != hipSuccess) {
+        *err = "hip: pe25d halo copy launch failed";
+        return GCM_ERR_HIP;
+    }
+    return GCM_OK;
+}
+
+const double *pe25d_field(Pe25d *m, int field, long *n) {
+    *n = (long)m->H * m->W * (field == GCM_P ? 1 : m->L);
+    return m->st[m->cur_i][field];
+}
+
+void pe25d_timing(Pe25d *m, std::vector<hipEvent_t> *ev, size_t *used) {
+    m->ev = ev;
+    m->ev_used = used;
+}
+
+}  // namespace gcm

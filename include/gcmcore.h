@@ -98,7 +98,7 @@ typedef struct {
     const double *dsig;    /* [L] */
     const double *sigb;    /* [L] */
     const double *sigt;    /* [L] */
-    const double *heightmap; /* [height][W] rows of THIS band, or NULL for flat topography       */
+    const double *heightmap; /* [global_height][W] (all rows), or NULL for flat topography       */
     void *stream;          /* hipStream_t to launch on; NULL = the null stream                   */
 } gcm_config;
 
