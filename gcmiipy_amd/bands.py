@@ -1,17 +1,22 @@
 """Latitude-band decomposition across the GPUs of one node.
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  The
-grid's H rows are split into contiguous bands; every step each rank sends the two
-rows at either edge of its band to its ring neighbours -- the ring closes between
-rank 0 and rank N-1 because the reference's np.roll along j is pole-to-pole
-periodic (coordinates.py:40-45) -- and meanwhile steps the interior rows that need
-no ghost data on the compute stream; the edge rows follow once the ghosts landed.
+grid's H rows are split into contiguous bands; ranks form a ring that closes between
+rank 0 and rank N-1 because the reference's np.roll along j is pole-to-pole periodic
+(coordinates.py:40-45).  Each exchange sends the two rows at either edge of a band
+to the two ring neighbours (point-to-point, no collective on the data path).
+
+  2-D models (fused Matsuno kernel): ONE exchange per step.  The interior rows,
+    which need no ghost data, are stepped on the compute stream while the exchange
+    runs on a second stream; the four edge rows follow once the ghosts landed.
+  GCM_PE25D: TWO exchanges per step -- the current state before the predictor, the
+    predicted state before the corrector (the corrector needs
+    the neighbour's *predicted* rows, which cannot be recomputed from a 2-row halo).
 
 `BandRunner` only orchestrates; the numerical work is behind an *engine*:
 `HipBandEngine` (the product: a `Core` with nranks > 1) or, in the CPU/gloo tests,
 a NumPy engine defined under tests/.
 """
-import numpy as np
 
 
 def split_rows(global_h, nranks):
@@ -29,11 +34,14 @@ class BandRunner:
     """Steps one band; `dist` is torch.distributed (initialised) or None for 1 rank.
 
     engine protocol:
-        send_buffer(side) -> tensor      pack the 2 edge rows of `side` (0 north, 1 south)
-        recv_buffer(side) -> tensor      where the neighbour's rows for that side land
-        unpack(side)                     recv_buffer(side) -> ghost rows
-        step_interior(dt), step_boundary(dt), step_all(dt)
-        comm_begin() / comm_end()        stream fencing around the exchange (GPU engines)
+        phases                          number of exchange+compute phases per step (1 or 2)
+        send_buffer(side) -> tensor     pack the 2 edge rows of `side` (0 north, 1 south)
+        recv_buffer(side) -> tensor     where the neighbour's rows for that side land
+        unpack(side)                    recv_buffer(side) -> ghost rows
+        compute_overlapped(phase, dt)   work that needs no ghost rows (may be a no-op)
+        compute_after(phase, dt)        the rest of the phase
+        step_all(dt)                    single-band step (nranks == 1)
+        comm_begin() / comm_end()       stream fencing around the exchange (GPU engines)
     """
 
     def __init__(self, engine, rank, nranks, dist=None):
@@ -57,27 +65,36 @@ class BandRunner:
         if self.n == 1:
             self.e.step_all(dt)
             return
-        reqs = self.exchange_start()
-        self.e.step_interior(dt)          # overlaps the exchange
-        for r in reqs:
-            r.wait()
-        self.e.comm_end()
-        self.e.unpack(0)
-        self.e.unpack(1)
-        self.e.step_boundary(dt)
+        for phase in range(self.e.phases):
+            reqs = self.exchange_start()
+            self.e.compute_overlapped(phase, dt)      # overlaps the exchange
+            for r in reqs:
+                r.wait()
+            self.e.comm_end()
+            self.e.unpack(0)
+            self.e.unpack(1)
+            self.e.compute_after(phase, dt)
 
 
 class HipBandEngine:
     """A `Core` band + torch CUDA buffers/streams for the exchange."""
 
-    def __init__(self, core, torch):
+    def __init__(self, core, torch, overlap=True, stream_aware=True):
+        """stream_aware: the backend orders its transfers after the current CUDA stream (nccl =
+        RCCL does).  For a backend that does not (gloo, used by the one-GPU test) the pack
+        kernels are host-synchronised before the send is posted."""
+        from . import _lib
+        self.stream_aware = stream_aware
         self.c, self.torch = core, torch
+        self.pe = core.model == _lib.PE25D
+        self.phases = 2 if self.pe else 1
         nbytes = core.halo_bytes()
         dev = torch.device("cuda", torch.cuda.current_device())
         mk = lambda: torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
         self.sbuf, self.rbuf = [mk(), mk()], [mk(), mk()]
         self.compute = torch.cuda.current_stream()
-        self.comm = torch.cuda.Stream()
+        self.comm = torch.cuda.Stream() if overlap else self.compute
+        self.overlap = overlap
         self._ctx = None
 
     def _s(self, stream):
@@ -85,6 +102,8 @@ class HipBandEngine:
 
     def send_buffer(self, side):
         self.c.halo_pack(side, self.sbuf[side].data_ptr(), self._s(self.compute))
+        if not self.stream_aware:
+            self.compute.synchronize()
         return self.sbuf[side]
 
     def recv_buffer(self, side):
@@ -94,27 +113,38 @@ class HipBandEngine:
         # the collective library orders its work after the *current* stream: make that
         # the comm stream, which waits for the pack kernels, so the interior step that
         # is launched next on the compute stream runs concurrently with the exchange
+        if not self.overlap:
+            return
         self.comm.wait_stream(self.compute)
         self._ctx = self.torch.cuda.stream(self.comm)
         self._ctx.__enter__()
 
-    def comm_end(self):
+    def _leave_comm(self):
         if self._ctx is not None:
             self._ctx.__exit__(None, None, None)
             self._ctx = None
-        self.compute.wait_stream(self.comm)
+
+    def comm_end(self):
+        self._leave_comm()
+        if self.overlap:
+            self.compute.wait_stream(self.comm)
 
     def unpack(self, side):
         self.c.halo_unpack(side, self.rbuf[side].data_ptr(), self._s(self.compute))
 
-    def step_interior(self, dt):
-        if self._ctx is not None:           # leave the comm-stream context for compute work
-            self._ctx.__exit__(None, None, None)
-            self._ctx = None
-        self.c.step_interior(dt, self._s(self.compute))
+    def compute_overlapped(self, phase, dt):
+        self._leave_comm()                  # compute work goes to the compute stream
+        if not self.pe:
+            self.c.step_interior(dt, self._s(self.compute))
 
-    def step_boundary(self, dt):
-        self.c.step_boundary(dt, self._s(self.compute))
+    def compute_after(self, phase, dt):
+        if self.pe:                         # phase 0: predictor, phase 1: corrector + swap
+            if phase == 0:
+                self.c.step_interior(dt, self._s(self.compute))
+            else:
+                self.c.step_boundary(dt, self._s(self.compute))
+        else:
+            self.c.step_boundary(dt, self._s(self.compute))
 
     def step_all(self, dt):
         self.c.step(1, dt)

@@ -1,0 +1,137 @@
+"""N > 1 path on the CPU: gcmiipy_amd.bands.BandRunner over torch.distributed/gloo with
+world_size 2 and 3, NumPy band engines (tests/band_engines.py).  The banded result must
+equal the single-domain oracle BIT FOR BIT (same arithmetic per row)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _ic2d(shape, temp):
+    rng = np.random.default_rng(5)
+    f = dict(u=rng.standard_normal(shape), v=rng.standard_normal(shape))
+    if temp:
+        f.update(p=101325 + rng.standard_normal(shape), t=273.16 + rng.standard_normal(shape),
+                 q=rng.random(shape))
+    else:
+        f.update(p=8000 + rng.standard_normal(shape))
+    return f
+
+
+def _worker_2d(rank, world, port, shape, temp, steps, outdir):
+    from band_engines import NumpyBand2D
+    from gcmiipy_amd.bands import BandRunner, split_rows
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = _ic2d(shape, temp)
+    row0, n = split_rows(shape[0], world)[rank]
+    log = []
+    eng = NumpyBand2D({k: v[row0:row0 + n] for k, v in full.items()}, 300e3, temp, log)
+    runner = BandRunner(eng, rank, world, dist)
+    for _ in range(steps):
+        runner.step(300.0)
+    # the runner must start the exchange, then the interior, then wait/unpack, then the boundary
+    assert log[:6] == ["comm_begin", "interior", "comm_end", "unpack0", "unpack1", "boundary"], log[:6]
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), **eng.interior_state())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _worker_pe(rank, world, port, hwl, steps, outdir):
+    from band_engines import NumpyBandPE
+    from gcmiipy_amd.bands import BandRunner, split_rows
+    from oracle import geometry as ogeo
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, W, L = hwl
+    geom = ogeo.gen_geometry(H, W, L, sig_func=ogeo.manabe_sig)
+    geom.heightmap[H // 2, 3] = 300.0
+    p, u, v, t, q = _ic_pe(geom)
+    row0, n = split_rows(H, world)[rank]
+    sl = slice(row0, row0 + n)
+    eng = NumpyBandPE(p[sl], u[:, sl], v[:, sl], t[:, sl], q[:, sl], geom, row0)
+    runner = BandRunner(eng, rank, world, dist)
+    for _ in range(steps):
+        runner.step(120.0)
+    st = eng.interior_state()
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), **dict(zip("puvtq", st)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _ic_pe(geom):
+    from oracle import temperature
+    rng = np.random.default_rng(9)
+    L, H, W = geom.layers, geom.height, geom.width
+    p = 1e5 + 10 * rng.standard_normal((H, W))
+    u = rng.standard_normal((L, H, W))
+    v = rng.standard_normal((L, H, W))
+    v[:, -1, :] = 0
+    t = temperature.to_potential_temp(300 + rng.standard_normal((L, H, W)), p * geom.sig + geom.ptop)
+    q = 3e-6 * (1 + 0.1 * rng.random((L, H, W)))
+    return p, u, v, t, q
+
+
+def test_split_rows():
+    from gcmiipy_amd.bands import split_rows
+    assert split_rows(720, 8) == [(90 * r, 90) for r in range(8)]
+    assert split_rows(10, 3) == [(0, 4), (4, 3), (7, 3)]
+    assert sum(n for _, n in split_rows(2048, 7)) == 2048
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("temp", [False, True])
+def test_banded_2d_equals_single_domain(tmp_path, world, temp):
+    from oracle import sw2d, sw2d_temp, tracer
+    shape, steps = (14, 24), 3
+    mp.spawn(_worker_2d, args=(world, _free_port(), shape, temp, steps, str(tmp_path)), nprocs=world,
+             join=True)
+    f = _ic2d(shape, temp)
+    for _ in range(steps):
+        if temp:
+            q = tracer.limited_advection(300.0, (300e3, 300e3), np.stack([f["v"], f["u"]]), f["q"])
+            u, v, p, t = sw2d_temp.matsumo_scheme(f["u"], f["v"], f["p"], f["t"], 300e3, 300.0)
+            f = dict(u=u, v=v, p=p, t=t, q=q)
+        else:
+            u, v, p = sw2d.matsumo_scheme(f["u"], f["v"], f["p"], 300e3, 300.0)
+            f = dict(u=u, v=v, p=p)
+    parts = [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(world)]
+    for k in f:
+        got = np.concatenate([pp[k] for pp in parts], axis=0)
+        assert np.array_equal(got, f[k]), k
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_banded_pe25d_equals_single_domain(tmp_path, world):
+    from oracle import dynamics, geometry as ogeo
+    hwl, steps = (12, 16, 3), 2
+    mp.spawn(_worker_pe, args=(world, _free_port(), hwl, steps, str(tmp_path)), nprocs=world, join=True)
+    H, W, L = hwl
+    geom = ogeo.gen_geometry(H, W, L, sig_func=ogeo.manabe_sig)
+    geom.heightmap[H // 2, 3] = 300.0
+    st = _ic_pe(geom)
+    for _ in range(steps):
+        st = dynamics.matsuno_timestep(*st, 120.0, geom)
+    parts = [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(world)]
+    for k, want in zip("puvtq", st):
+        got = np.concatenate([pp[k] for pp in parts], axis=0 if k == "p" else 1)
+        assert np.array_equal(got, want), k

@@ -1,0 +1,196 @@
+"""GPU tests of the latitude-band path: (A) several bands of one grid stepped in ONE process
+on one GPU with the ghost rows moved by device copies -- exercises the ghost-row kernels,
+gcm_halo_pack/unpack and gcm_step_interior/boundary against the single-band result; (B) two
+processes sharing the GPU, BandRunner + HipBandEngine over torch.distributed (gloo here: RCCL
+refuses two ranks on one device; the 8-GPU run uses the same code with backend nccl)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _ic2d(shape):
+    rng = np.random.default_rng(11)
+    return dict(u=rng.standard_normal(shape), v=rng.standard_normal(shape),
+                p=101325 + rng.standard_normal(shape), t=273.16 + rng.standard_normal(shape),
+                q=rng.random(shape))
+
+
+def _ic_pe(geom):
+    rng = np.random.default_rng(12)
+    L, H, W = geom.layers, geom.height, geom.width
+    p = 1e5 + 10 * rng.standard_normal((H, W))
+    u = rng.standard_normal((L, H, W))
+    v = rng.standard_normal((L, H, W))
+    v[:, -1, :] = 0
+    sig = np.asarray(geom.sig)
+    t = (300 + rng.standard_normal((L, H, W))) * ((1e5 / (p * sig + geom.ptop)) ** (287.0 / 1004.0))
+    q = 3e-6 * (1 + 0.1 * rng.random((L, H, W)))
+    return p, u, v, t, q
+
+
+def _exchange(cores, torch):
+    """ring exchange by device copies: the rows a band packs on side s land in the neighbour's
+    opposite ghost"""
+    n = len(cores)
+    bufs = [[torch.empty(c.halo_bytes() // 8, dtype=torch.float64, device="cuda") for _ in (0, 1)]
+            for c in cores]
+    for r, c in enumerate(cores):
+        c.halo_pack(0, bufs[r][0].data_ptr())
+        c.halo_pack(1, bufs[r][1].data_ptr())
+    torch.cuda.synchronize()
+    for r, c in enumerate(cores):
+        c.halo_unpack(1, bufs[(r + 1) % n][0].data_ptr())   # south ghost <- southern band's north edge
+        c.halo_unpack(0, bufs[(r - 1) % n][1].data_ptr())   # north ghost <- northern band's south edge
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("variant", ["fused", "staged"])
+@pytest.mark.parametrize("nb", [2, 3])
+def test_bands_in_process_2d(variant, nb):
+    import torch
+    import gcmiipy_amd as g
+    from gcmiipy_amd.bands import split_rows
+    H, W, steps = 37, 130, 3
+    var = g._lib.VARIANT_FUSED if variant == "fused" else g._lib.VARIANT_STAGED
+    f = _ic2d((H, W))
+    ref = g.Core(g._lib.SW2D_TEMP, W, H, dx=300e3, tracer=g._lib.TRACER_VANLEER, variant=var)
+    ref.set_state(**f)
+    ref.step(steps, 300.0)
+    want = ref.get_state()
+    ref.close()
+    cores = []
+    for r, (row0, n) in enumerate(split_rows(H, nb)):
+        c = g.Core(g._lib.SW2D_TEMP, W, n, dx=300e3, tracer=g._lib.TRACER_VANLEER, variant=var,
+                   nranks=nb, rank=r, global_height=H, row0=row0)
+        c.set_state(**{k: v[row0:row0 + n] for k, v in f.items()})
+        cores.append(c)
+    for _ in range(steps):
+        _exchange(cores, torch)
+        for c in cores:
+            c.step_interior(300.0)
+        for c in cores:
+            c.step_boundary(300.0)
+    got = [np.concatenate(x, axis=0) for x in zip(*[c.get_state() for c in cores])]
+    for c in cores:
+        c.close()
+    for k, a, b in zip("puvtq", got, want):
+        assert rel_err(a, b) < 1e-13, (k, rel_err(a, b))
+
+
+@pytest.mark.parametrize("nb", [2, 3])
+def test_bands_in_process_pe25d(nb):
+    import torch
+    import gcmiipy_amd as g
+    from gcmiipy_amd import geometry
+    from gcmiipy_amd.bands import split_rows
+    H, W, L, steps = 14, 20, 5, 2
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    geom.heightmap[H // 2, 3] = 300.0
+    ic = _ic_pe(geom)
+    ref = g.Core(g._lib.PE25D, W, H, L, geom=geom)
+    ref.set_state(*ic)
+    ref.step(steps, 120.0)
+    want = ref.get_state()
+    ref.close()
+    cores = []
+    for r, (row0, n) in enumerate(split_rows(H, nb)):
+        c = g.Core(g._lib.PE25D, W, n, L, geom=geom, nranks=nb, rank=r, global_height=H, row0=row0)
+        sl = slice(row0, row0 + n)
+        c.set_state(ic[0][sl], *[a[:, sl] for a in ic[1:]])
+        cores.append(c)
+    for _ in range(steps):
+        _exchange(cores, torch)          # current state
+        for c in cores:
+            c.step_interior(120.0)       # predictor
+        _exchange(cores, torch)          # predicted state
+        for c in cores:
+            c.step_boundary(120.0)       # corrector
+    parts = [c.get_state() for c in cores]
+    for c in cores:
+        c.close()
+    for f, k in enumerate("puvtq"):
+        got = np.concatenate([p_[f] for p_ in parts], axis=0 if f == 0 else 1)
+        assert rel_err(got, want[f]) < 1e-13, (k, rel_err(got, want[f]))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, model, outdir):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import gcmiipy_amd as g
+    from gcmiipy_amd import geometry
+    from gcmiipy_amd.bands import BandRunner, HipBandEngine, split_rows
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if model == "c3":
+        H, W, steps, dt = 40, 130, 3, 300.0
+        f = _ic2d((H, W))
+        row0, n = split_rows(H, world)[rank]
+        c = g.Core(g._lib.SW2D_TEMP, W, n, dx=300e3, tracer=g._lib.TRACER_VANLEER, nranks=world, rank=rank,
+                   global_height=H, row0=row0, stream=torch.cuda.current_stream().cuda_stream)
+        c.set_state(**{k: v[row0:row0 + n] for k, v in f.items()})
+    else:
+        H, W, L, steps, dt = 14, 20, 5, 2, 120.0
+        geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+        ic = _ic_pe(geom)
+        row0, n = split_rows(H, world)[rank]
+        sl = slice(row0, row0 + n)
+        c = g.Core(g._lib.PE25D, W, n, L, geom=geom, nranks=world, rank=rank, global_height=H, row0=row0,
+                   stream=torch.cuda.current_stream().cuda_stream)
+        c.set_state(ic[0][sl], *[a[:, sl] for a in ic[1:]])
+    runner = BandRunner(HipBandEngine(c, torch, stream_aware=False), rank, world, dist)
+    for _ in range(steps):
+        runner.step(dt)
+    torch.cuda.synchronize()
+    st = c.get_state()
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), **{k: a for k, a in zip("puvtq", st) if a is not None})
+    c.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", ["c3", "pe"])
+def test_band_runner_two_processes_one_gpu(tmp_path, model):
+    import torch.multiprocessing as mp
+    import gcmiipy_amd as g
+    from gcmiipy_amd import geometry
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), model, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(world)]
+    if model == "c3":
+        H, W = 40, 130
+        ref = g.Core(g._lib.SW2D_TEMP, W, H, dx=300e3, tracer=g._lib.TRACER_VANLEER)
+        ref.set_state(**_ic2d((H, W)))
+        ref.step(3, 300.0)
+    else:
+        H, W, L = 14, 20, 5
+        geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+        ref = g.Core(g._lib.PE25D, W, H, L, geom=geom)
+        ref.set_state(*_ic_pe(geom))
+        ref.step(2, 120.0)
+    want = ref.get_state()
+    ref.close()
+    for f, k in enumerate("puvtq"):
+        axis = 1 if (model == "pe" and f > 0) else 0
+        got = np.concatenate([p_[k] for p_ in parts], axis=axis)
+        assert rel_err(got, want[f]) < 1e-13, (k, rel_err(got, want[f]))
