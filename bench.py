@@ -28,13 +28,29 @@ WORKLOADS = {
            "(BASELINE configs[2])", 2048, 4096, "SW2D_TEMP", "van_leer", 80.0),
     "c2": ("2-D shallow water Matsuno C-grid, 720x360 fp64 (BASELINE configs[1])",
            360, 720, "SW2D", None, 48.0),
+    # cells are (k, j, i) points; 4 3-D fields + p: (64 + 16/L) bytes per cell-update
+    "c4": ("2.5-D sigma-level primitive equations, 1440x720x24 fp64 (BASELINE configs[3])",
+           720, 1440, "PE25D", None, 64.0 + 16.0 / 24),
 }
+LAYERS = {"c4": 24}
 
 
-def synth(name, H, W, row0=0, nrows=None):
+def synth(name, H, W, row0=0, nrows=None, geom=None):
     """SURVEY.md 8d synthetic inputs, seed default_rng(0); rows [row0,row0+nrows) only."""
     rng = np.random.default_rng(0)
     nrows = H if nrows is None else nrows
+    if name == "c4":
+        L = LAYERS[name]
+        sl = slice(row0, row0 + nrows)
+        p = 1e5 + 10 * rng.standard_normal((H, W))
+        u = rng.standard_normal((L, H, W))
+        v = rng.standard_normal((L, H, W))
+        v[:, -1, :] = 0
+        tt = 300 + rng.standard_normal((L, H, W))
+        tp = p * np.asarray(geom.sig) + geom.ptop
+        t = tt * ((1e5 / tp) ** (287.0 / 1004.0))          # to_potential_temp, temperature.py:15-19
+        q = 3e-6 * (1 + 0.1 * rng.random((L, H, W)))
+        return dict(p=p[sl], u=u[:, sl], v=v[:, sl], t=t[:, sl], q=q[:, sl])
     u = rng.standard_normal((H, W))
     v = rng.standard_normal((H, W))
     sl = slice(row0, row0 + nrows)
@@ -50,6 +66,20 @@ def synth(name, H, W, row0=0, nrows=None):
 def cpu_baseline(name, H, W):
     """the oracle (NumPy restatement, bit-identical to the reference) on the host, 1 core"""
     from oracle import sw2d, sw2d_temp, tracer
+    if name == "c4":
+        # bounded sample: the same recipe on a 360x180x24 grid (1/16 of the cells), 2 steps
+        from oracle import dynamics, geometry as ogeo
+        h, w, L = 180, 360, LAYERS[name]
+        og = ogeo.gen_geometry(h, w, L, sig_func=ogeo.manabe_sig)
+        s = synth(name, h, w, geom=og)
+        st = (s["p"], s["u"], s["v"], s["t"], s["q"])
+        t0 = time.perf_counter()
+        for _ in range(2):
+            st = dynamics.matsuno_timestep(*st, 1.0, og)
+        el = time.perf_counter() - t0
+        return {"value": h * w * L * 2 / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+                "sample": "2 steps of a 360x180x24 grid (1/16 of the cells, same recipe) with the NumPy "
+                          "oracle, %.1f s; host has %d cores" % (el, os.cpu_count())}
     s = synth(name, H, W)
     dx, dt = 300e3, 300.0
     t0 = time.perf_counter()
@@ -99,12 +129,17 @@ def main():
     desc, H, W, model, tracer, bpc = WORKLOADS[a.workload]
     row0, nrows = split_rows(H, world)[rank]
     dx, dt = 300e3, 300.0
-    core = g.Core(getattr(_lib, model), W, nrows, dx=dx,
+    geom, L = None, 1
+    if model == "PE25D":
+        from gcmiipy_amd import geometry
+        L, dt = LAYERS[a.workload], 1.0
+        geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    core = g.Core(getattr(_lib, model), W, nrows, L, dx=dx, geom=geom,
                   tracer={None: _lib.TRACER_NONE, "van_leer": _lib.TRACER_VANLEER}[tracer],
                   variant=_lib.VARIANT_FUSED if a.variant == "fused" else _lib.VARIANT_STAGED,
                   nranks=world, rank=rank, global_height=H, row0=row0, device=local,
                   stream=torch.cuda.current_stream().cuda_stream)
-    core.set_state(**synth(a.workload, H, W, row0, nrows))
+    core.set_state(**synth(a.workload, H, W, row0, nrows, geom))
     runner = BandRunner(HipBandEngine(core, torch) if world > 1 else None, rank, world, dist)
 
     region = {}
@@ -138,7 +173,7 @@ def main():
 
     out = None
     if rank == 0:
-        cells = H * W
+        cells = H * W * L
         value = cells * a.steps / el
         out = {
             "metric": "cell-updates/s (C-grid Matsuno step)", "value": value,
@@ -157,15 +192,20 @@ def main():
         # "kernel_ms_isolated" is a second pass with an event pair around every launch
         # (idle gaps between launches let the chip clock higher, so it reads lower).
         _, kiso = core.time_steps(min(a.steps, 50), dt)
-        if a.variant == "fused":
+        launches = 1
+        if model == "PE25D":
+            # dominant kernel = pe_update_kernel, launched twice per step (once per Euler stage);
+            # its algorithmic bytes per launch are half of the step's
+            kname, kms, launches = "pe_update_kernel", kiso, 2
+        elif a.variant == "fused":
             kname, kms = "sw2d_fused_kernel", region["ms"] / a.steps
         else:
             kname, kms = "sw2d_stage_kernel (corrector stage)", kiso
-        ach = H * W * bpc / (kms * 1e-3) / 1e9
+        ach = H * W * L * bpc / launches / (kms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
                            "kernel_ms": kms, "kernel_ms_isolated": kiso,
-                           "algorithmic_bytes_per_launch": H * W * bpc}
+                           "algorithmic_bytes_per_launch": H * W * L * bpc / launches}
         out["cpu_baseline"] = None if a.no_cpu else cpu_baseline(a.workload, H, W)
     core.close()
     if dist is not None:
