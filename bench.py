@@ -135,6 +135,7 @@ def main():
         L, dt = LAYERS[a.workload], 1.0
         geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
     core = g.Core(getattr(_lib, model), W, nrows, L, dx=dx, geom=geom,
+                  filter=not os.environ.get("GCM_BENCH_NOFILTER"),   # diagnostic only
                   tracer={None: _lib.TRACER_NONE, "van_leer": _lib.TRACER_VANLEER}[tracer],
                   variant=_lib.VARIANT_FUSED if a.variant == "fused" else _lib.VARIANT_STAGED,
                   nranks=world, rank=rank, global_height=H, row0=row0, device=local,

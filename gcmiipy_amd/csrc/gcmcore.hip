@@ -180,6 +180,27 @@ int gcm_create(const gcm_config *cfg, gcm_handle **out) {
             h->rows_per_band = sw2d_fused_rows_per_band(h->W, h->H, temp, h->has[GCM_Q] ? cfg->tracer : 0, h->wrap);
             break;
         }
+        case GCM_PE2D: {
+            if (!(cfg->dx > 0)) return bail(GCM_ERR_ARG, "gcm_create: dx must be > 0");
+            if (cfg->nranks != 1)
+                return bail(GCM_ERR_UNSUPPORTED, "gcm_create: GCM_PE2D has no latitude-band mode");
+            h->variant = GCM_VARIANT_STAGED;
+            for (int f = 0; f < GCM_NFIELDS; ++f) {
+                h->has[f] = true;
+                if ((rc = alloc_field(h, &h->cur[f]))) return bail(rc, "");
+                if ((rc = alloc_field(h, &h->nxt[f]))) return bail(rc, "");
+                if ((rc = alloc_field(h, &h->star[f]))) return bail(rc, "");
+            }
+            double tab[kExnerTabDoubles];
+            build_exner_table(tab);
+            void *d = nullptr;
+            if (hipMalloc(&d, sizeof tab) != hipSuccess ||
+                hipMemcpy(d, tab, sizeof tab, hipMemcpyHostToDevice) != hipSuccess)
+                return bail(GCM_ERR_HIP, "gcm_create: exner table upload failed");
+            h->allocs.push_back(d);
+            h->exner_tab = (double *)d;
+            break;
+        }
         case GCM_PE25D: {
             std::string msg;
             h->pe = pe25d_create(*cfg, h->stream, &msg);
@@ -239,7 +260,14 @@ int gcm_set_star(gcm_handle *h, const double *p, const double *u, const double *
                  const double *t, const double *q) {
     if (!h) return GCM_ERR_ARG;
     if (h->pe) return pe25d_set(h->pe, true, p, u, v, t, q, &h->err);
-    if (q) return fail(h, GCM_ERR_ARG, "set_star: the tracer has no predicted state");
+    if (q && h->cfg.model != GCM_PE2D)
+        return fail(h, GCM_ERR_ARG, "set_star: the tracer has no predicted state");
+    if (h->cfg.model == GCM_PE2D) {
+        const double *src5[GCM_NFIELDS] = {p, u, v, t, q};
+        int rc5 = xfer(h, h->star, src5, nullptr, true);
+        if (rc5 == GCM_OK) h->star_valid = true;
+        return rc5;
+    }
     const double *src[GCM_NFIELDS] = {p, u, v, t, nullptr};
     int rc = xfer(h, h->star, src, nullptr, true);
     if (rc == GCM_OK) h->star_valid = true;
@@ -250,6 +278,10 @@ int gcm_get_star(gcm_handle *h, double *p, double *u, double *v, double *t, doub
     if (!h) return GCM_ERR_ARG;
     if (h->pe) return pe25d_get(h->pe, true, p, u, v, t, q, &h->err);
     if (!h->star_valid) return fail(h, GCM_ERR_STATE, "get_star: no predicted state yet");
+    if (h->cfg.model == GCM_PE2D) {
+        double *dst5[GCM_NFIELDS] = {p, u, v, t, q};
+        return xfer(h, h->star, nullptr, dst5, false);
+    }
     if (q) return fail(h, GCM_ERR_ARG, "get_star: the tracer has no predicted state");
     double *dst[GCM_NFIELDS] = {p, u, v, t, nullptr};
     return xfer(h, h->star, nullptr, dst, false);
@@ -290,6 +322,11 @@ static void tick(gcm_handle *h, hipStream_t s) {
 
 // predictor (stage 0) or corrector (stage 1) of the staged variant over rows [j0, j1)
 static void staged_stage(gcm_handle *h, int stage, double dt, int j0, int j1, hipStream_t s) {
+    if (h->cfg.model == GCM_PE2D) {
+        launch_pe2d_stage(h->cur, stage == 0 ? h->cur : h->star, stage == 0 ? h->star : h->nxt,
+                          h->exner_tab, h->W, h->H, dt, h->cfg.dx, s);
+        return;
+    }
     const bool temp = h->cfg.model == GCM_SW2D_TEMP;
     double *const *S = stage == 0 ? h->cur : h->star;
     double *const *O = stage == 0 ? h->star : h->nxt;
@@ -322,7 +359,7 @@ static void staged_stage(gcm_handle *h, int stage, double dt, int j0, int j1, hi
 }
 
 static void staged_tracer(gcm_handle *h, double dt, int j0, int j1, hipStream_t s) {
-    if (!h->has[GCM_Q]) return;
+    if (!h->has[GCM_Q] || h->cfg.model == GCM_PE2D) return;
     const bool lim = h->cfg.tracer == GCM_TRACER_VANLEER;
     Sw2dArgs a = base_args(h, dt);
     a.j0 = j0;

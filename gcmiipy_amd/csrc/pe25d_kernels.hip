@@ -27,6 +27,7 @@ constexpr int kMaxRadices = 24;
 struct FftPlan {
     int n, nrad;
     int rad[kMaxRadices];
+    unsigned magic[kMaxRadices];   // ceil(2^32 / Ns) per pass: b / Ns == umulhi(b, magic) for b*Ns < 2^32
 };
 
 struct PeArgs {
@@ -70,6 +71,20 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+// -i z (forward transforms) or +i z (inverse)
+template <bool INV>
+__device__ __forceinline__ double2 rot(double2 z) {
+    return INV ? make_double2(-z.y, z.x) : make_double2(z.y, -z.x);
+}
+template <bool INV>
+__device__ __forceinline__ double2 twid(const double2 *tw, int idx) {
+    double2 w = tw[idx];
+    if (INV) w.y = -w.y;
+    return w;
+}
+
 template <bool INV>
 __device__ double2 *fft_lds(double2 *x, double2 *y, const double2 *tw, const FftPlan &P) {
     const int N = P.n;
@@ -78,42 +93,64 @@ __device__ double2 *fft_lds(double2 *x, double2 *y, const double2 *tw, const Fft
         const int r = P.rad[pass];
         const int nb = N / r;
         const int tstep = N / (Ns * r);  // twiddle index step
+        const unsigned magic = P.magic[pass];
         for (int b = threadIdx.x; b < nb; b += blockDim.x) {
-            const int k = b % Ns;
-            const int j0 = (b / Ns) * Ns * r + k;
+            const int blk = Ns == 1 ? b : (int)__umulhi((unsigned)b, magic);
+            const int k = b - blk * Ns;
+            const int j0 = blk * Ns * r + k;
+            const int t1 = k * tstep;
             if (r == 2) {
-                double2 a0 = x[b], a1 = x[b + nb];
-                double2 w = tw[k * tstep];
-                if (INV) w.y = -w.y;
-                a1 = cmul(a1, w);
-                y[j0] = make_double2(a0.x + a1.x, a0.y + a1.y);
-                y[j0 + Ns] = make_double2(a0.x - a1.x, a0.y - a1.y);
+                const double2 a0 = x[b], a1 = cmul(x[b + nb], twid<INV>(tw, t1));
+                y[j0] = cadd(a0, a1);
+                y[j0 + Ns] = csub(a0, a1);
             } else if (r == 4) {
-                double2 a0 = x[b], a1 = x[b + nb], a2 = x[b + 2 * nb], a3 = x[b + 3 * nb];
-                double2 w1 = tw[k * tstep], w2 = tw[2 * k * tstep], w3 = tw[3 * k * tstep];
-                if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
-                a1 = cmul(a1, w1);
-                a2 = cmul(a2, w2);
-                a3 = cmul(a3, w3);
-                const double2 s02 = make_double2(a0.x + a2.x, a0.y + a2.y);
-                const double2 d02 = make_double2(a0.x - a2.x, a0.y - a2.y);
-                const double2 s13 = make_double2(a1.x + a3.x, a1.y + a3.y);
-                const double2 d13 = make_double2(a1.x - a3.x, a1.y - a3.y);
-                // forward: -i * d13 = (d13.y, -d13.x); inverse: +i * d13 = (-d13.y, d13.x)
-                const double2 jd = INV ? make_double2(-d13.y, d13.x) : make_double2(d13.y, -d13.x);
-                y[j0] = make_double2(s02.x + s13.x, s02.y + s13.y);
-                y[j0 + Ns] = make_double2(d02.x + jd.x, d02.y + jd.y);
-                y[j0 + 2 * Ns] = make_double2(s02.x - s13.x, s02.y - s13.y);
-                y[j0 + 3 * Ns] = make_double2(d02.x - jd.x, d02.y - jd.y);
+                const double2 a0 = x[b];
+                const double2 a1 = cmul(x[b + nb], twid<INV>(tw, t1));
+                const double2 a2 = cmul(x[b + 2 * nb], twid<INV>(tw, 2 * t1));
+                const double2 a3 = cmul(x[b + 3 * nb], twid<INV>(tw, 3 * t1));
+                const double2 s02 = cadd(a0, a2), d02 = csub(a0, a2);
+                const double2 s13 = cadd(a1, a3), jd = rot<INV>(csub(a1, a3));
+                y[j0] = cadd(s02, s13);
+                y[j0 + Ns] = cadd(d02, jd);
+                y[j0 + 2 * Ns] = csub(s02, s13);
+                y[j0 + 3 * Ns] = csub(d02, jd);
+            } else if (r == 3) {
+                const double2 a0 = x[b];
+                const double2 a1 = cmul(x[b + nb], twid<INV>(tw, t1));
+                const double2 a2 = cmul(x[b + 2 * nb], twid<INV>(tw, 2 * t1));
+                const double2 t = cadd(a1, a2);
+                const double2 m = make_double2(a0.x - 0.5 * t.x, a0.y - 0.5 * t.y);
+                double2 sv = rot<INV>(csub(a1, a2));
+                sv.x *= 0.86602540378443864676;  // sin(2 pi / 3)
+                sv.y *= 0.86602540378443864676;
+                y[j0] = cadd(a0, t);
+                y[j0 + Ns] = cadd(m, sv);
+                y[j0 + 2 * Ns] = csub(m, sv);
+            } else if (r == 5) {
+                constexpr double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+                constexpr double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+                const double2 a0 = x[b];
+                const double2 a1 = cmul(x[b + nb], twid<INV>(tw, t1));
+                const double2 a2 = cmul(x[b + 2 * nb], twid<INV>(tw, 2 * t1));
+                const double2 a3 = cmul(x[b + 3 * nb], twid<INV>(tw, 3 * t1));
+                const double2 a4 = cmul(x[b + 4 * nb], twid<INV>(tw, 4 * t1));
+                const double2 p1 = cadd(a1, a4), p2 = cadd(a2, a3), q1 = csub(a1, a4), q2 = csub(a2, a3);
+                const double2 m1 = make_double2(a0.x + c1 * p1.x + c2 * p2.x, a0.y + c1 * p1.y + c2 * p2.y);
+                const double2 m2 = make_double2(a0.x + c2 * p1.x + c1 * p2.x, a0.y + c2 * p1.y + c1 * p2.y);
+                const double2 n1 = rot<INV>(make_double2(s1 * q1.x + s2 * q2.x, s1 * q1.y + s2 * q2.y));
+                const double2 n2 = rot<INV>(make_double2(s2 * q1.x - s1 * q2.x, s2 * q1.y - s1 * q2.y));
+                y[j0] = cadd(a0, cadd(p1, p2));
+                y[j0 + Ns] = cadd(m1, n1);
+                y[j0 + 2 * Ns] = cadd(m2, n2);
+                y[j0 + 3 * Ns] = csub(m2, n2);
+                y[j0 + 4 * Ns] = csub(m1, n1);
             } else {
                 // generic radix: out[q] = sum_m (x_m w^(m k)) W_r^(q m), W_r^t = tw[(t mod r) N/r]
                 const int rstep = N / r;
                 for (int qq = 0; qq < r; ++qq) {
                     double2 acc = make_double2(0.0, 0.0);
                     for (int m = 0; m < r; ++m) {
-                        double2 w = tw[(m * k * tstep + ((qq * m) % r) * rstep) % N];
-                        if (INV) w.y = -w.y;
-                        const double2 t = cmul(x[b + m * nb], w);
+                        const double2 t = cmul(x[b + m * nb], twid<INV>(tw, (m * t1 + ((qq * m) % r) * rstep) % N));
                         acc.x += t.x;
                         acc.y += t.y;
                     }
@@ -445,6 +482,11 @@ static bool make_plan(int n, FftPlan *P) {
     while (m % 2 == 0) { push(2); m /= 2; }
     for (int r = 3; r <= m && m > 1; r += 2)
         while (m % r == 0) { push(r); m /= r; }
+    long Ns = 1;
+    for (int i = 0; i < P->nrad; ++i) {
+        P->magic[i] = (unsigned)(((1ULL << 32) + (unsigned long long)Ns - 1) / (unsigned long long)Ns);
+        Ns *= P->rad[i];
+    }
     return m == 1 && P->nrad <= kMaxRadices;
 }
 

@@ -35,6 +35,10 @@ void launch_tracer_axis(const Sw2dArgs &a, int axis, bool limit, const double *q
 void launch_sw2d_fused(const Sw2dArgs &a, bool temp, int tracer, hipStream_t s);
 int sw2d_fused_rows_per_band(int W, int H, bool temp, int tracer, bool wrap);
 
+// GCM_PE2D: one Euler stage; base/stage/out are {p,u,v,t,q} interior pointers (wrap only)
+void launch_pe2d_stage(const double *const base[5], const double *const stage[5], double *const out[5],
+                       const double *exner_tab, int W, int H, double dt, double dx, hipStream_t s);
+
 // fills tab[256] (host) for gcm_math.h's exner(); kappa and P0 as in constants.py:28,31
 void build_exner_table(double *tab);
 
