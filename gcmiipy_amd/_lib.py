@@ -16,6 +16,7 @@ SW2D, SW2D_TEMP, PE2D, PE25D = 1, 2, 3, 4
 P, U, V, T, Q = 0, 1, 2, 3, 4
 TRACER_NONE, TRACER_UPWIND, TRACER_VANLEER = 0, 1, 2
 VARIANT_AUTO, VARIANT_STAGED, VARIANT_FUSED = 0, 1, 2
+ADV_UPWIND, ADV_FV_UPWIND, ADV_FV_PLAIN, ADV_VANLEER, ADV_MOMENTUM = range(5)
 DIAG_ANY_NAN, DIAG_MAX_U, DIAG_MEAN_P, DIAG_SUM_P, DIAG_MIN_U, DIAG_MAX_V, DIAG_MIN_V = range(7)
 OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 
@@ -58,6 +59,9 @@ SYMBOLS = {
     "gcm_step_interior": (C.c_int, [_H, C.c_double, C.c_void_p]),
     "gcm_step_boundary": (C.c_int, [_H, C.c_double, C.c_void_p]),
     "gcm_sync": (C.c_int, [_H]),
+    "gcm_advect2d": (C.c_int, [C.c_int] * 6 + [C.c_double] * 3 + [C.c_void_p] * 3),
+    "gcm_pgf2d": (C.c_int, [C.c_int] * 3 + [C.c_double] * 3 + [C.c_void_p] * 3),
+    "gcm_ops_last_error": (C.c_char_p, []),
     "gcm_time_steps": (C.c_int, [_H, C.c_int, C.c_double, _dp, _dp]),
 }
 

@@ -1,0 +1,192 @@
+// Stand-alone 2-D C-grid operators of the reference's two_d.py on velocity stacks V[axis]
+// (V[0] acts along array axis 0 = rows, with spatial_change[0]; two_d.py:16-22):
+//   gcm_advect2d  upwind_axis / corner_transport_2d (:11-71), fv_advect_axis_upwind /
+//                 finite_volume_advection (:103-132,198-207), fv_advect_axis_plain (:135-166),
+//                 advect_with_momentum (:277-292), + the van-Leer-limited composition
+//   gcm_pgf2d     pgf_c_grid_axis / pgf_c_grid / pgf_templess / pressure_at_edge (:210-274)
+// Host pointers in, host pointers out (the reference's call shape); the field stays on the
+// device for all `nsteps`.
+#include "../../include/gcmcore.h"
+#include "gcm_math.h"
+#include "sw2d_kernels.h"
+
+#include <string>
+#include <vector>
+
+namespace gcm {
+
+struct AdvArgs {
+    const double *vel;     // V[axis], [H][W]
+    const double *qin;
+    double *qout;
+    int W, H;
+    double dt, dx, dtdx, area, volume;
+};
+
+__device__ __forceinline__ long at2(int j, int i, int H, int W) {
+    j %= H; if (j < 0) j += H;
+    i %= W; if (i < 0) i += W;
+    return (long)j * W + i;
+}
+
+// SCHEME: 0 upwind_axis (non-conservative), 1 fv upwind, 2 fv plain (centred), 3 van Leer
+template <int AXIS, int SCHEME, bool FINITE>
+__global__ __launch_bounds__(256) void advect_axis_kernel(AdvArgs a) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= a.W || j >= a.H) return;
+    const int H = a.H, W = a.W;
+    auto Q = [&](int d) { return a.qin[AXIS == 0 ? at2(j + d, i, H, W) : at2(j, i + d, H, W)]; };
+    auto VEL = [&](int d) { return a.vel[AXIS == 0 ? at2(j + d, i, H, W) : at2(j, i + d, H, W)]; };
+    const double q0 = Q(0), qm = Q(-1), qp = Q(1);
+    const double v0 = VEL(0);
+    double res;
+    if (SCHEME == 0) {                                   // two_d.py:11-55
+        const double a_plus = fmax(v0, 0.0), a_minus = fmin(v0, 0.0);
+        const double mult = a_plus * (q0 - qm) + a_minus * (qp - q0);
+        const double fin = mult * (a.dt / a.dx);
+        res = FINITE ? fin : q0 - fin;
+    } else if (SCHEME == 2) {                            // two_d.py:135-166
+        const double vm = VEL(-1);
+        const double flux = v0 * ((q0 + qp) * 0.5) * a.dt * a.area;
+        const double fm = vm * ((qm + q0) * 0.5) * a.dt * a.area;
+        res = FINITE ? fm - flux : q0 - (flux - fm) / a.volume;
+    } else {                                             // two_d.py:103-132 (+ limiter)
+        const double vm = VEL(-1);
+        const double qmm = SCHEME == 3 ? Q(-2) : 0.0, qpp = SCHEME == 3 ? Q(2) : 0.0;
+        const double flux = face_flux<SCHEME == 3>(v0, qm, q0, qp, qpp, a.dtdx);
+        const double fm = face_flux<SCHEME == 3>(vm, qmm, qm, q0, qp, a.dtdx);
+        res = FINITE ? fm - flux : q0 - flux + fm;
+    }
+    a.qout[(long)j * W + i] = res;
+}
+
+// momentum = V * pressure_at_edge(p): edge average along the velocity's own axis (two_d.py:264-279)
+__global__ __launch_bounds__(256) void momentum_kernel(double *m0, double *m1, const double *v0, const double *v1,
+                                                      const double *p, int W, int H) {
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= W || j >= H) return;
+    const long o = (long)j * W + i;
+    m0[o] = v0[o] * ((p[at2(j + 1, i, H, W)] + p[o]) * 0.5);
+    m1[o] = v1[o] * ((p[at2(j, i + 1, H, W)] + p[o]) * 0.5);
+}
+
+// kind: 0 pgf_c_grid_axis gradients only, 1 pgf_c_grid (needs t), 2 pgf_templess, 3 pressure_at_edge
+__global__ __launch_bounds__(256) void pgf_kernel(double *o0, double *o1, const double *p, const double *t,
+                                                 const double *etab, int kind, int W, int H, double dt,
+                                                 double dx0, double dx1) {
+    __shared__ double tab[kExnerTabDoubles];
+    tab[threadIdx.y * 64 + threadIdx.x] = etab[threadIdx.y * 64 + threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= W || j >= H) return;
+    const long o = (long)j * W + i;
+    const double pc = p[o], ps = p[at2(j + 1, i, H, W)], pe = p[at2(j, i + 1, H, W)];
+    const double g0 = (ps - pc) / dx0, g1 = (pe - pc) / dx1;           // two_d.py:210-220
+    if (kind == 0) {
+        o0[o] = g0; o1[o] = g1;
+    } else if (kind == 1) {                                           // two_d.py:223-245
+        const double true_t = t[o] * exner(pc, tab);                  // t / (P0/p)**kappa
+        const double rho = pc / (kRd * true_t);
+        o0[o] = g0 / rho * dt; o1[o] = g1 / rho * dt;
+    } else if (kind == 2) {                                           // two_d.py:248-261
+        const double d0 = ((ps + pc) * 0.5) / (kRd * 273.16), d1 = ((pe + pc) * 0.5) / (kRd * 273.16);
+        o0[o] = g0 * dt / d0; o1[o] = g1 * dt / d1;
+    } else {                                                          // two_d.py:264-268
+        o0[o] = (ps + pc) * 0.5; o1[o] = (pe + pc) * 0.5;
+    }
+}
+
+template <int AXIS, bool FIN>
+static void launch_axis(int scheme, const AdvArgs &a, dim3 g, dim3 b) {
+    switch (scheme) {
+        case 0: hipLaunchKernelGGL((advect_axis_kernel<AXIS, 0, FIN>), g, b, 0, nullptr, a); break;
+        case 1: hipLaunchKernelGGL((advect_axis_kernel<AXIS, 1, FIN>), g, b, 0, nullptr, a); break;
+        case 2: hipLaunchKernelGGL((advect_axis_kernel<AXIS, 2, FIN>), g, b, 0, nullptr, a); break;
+        default: hipLaunchKernelGGL((advect_axis_kernel<AXIS, 3, FIN>), g, b, 0, nullptr, a); break;
+    }
+}
+
+}  // namespace gcm
+
+using namespace gcm;
+
+namespace {
+struct DevBuf {
+    std::vector<void *> v;
+    ~DevBuf() { for (void *p : v) (void)hipFree(p); }
+    double *get(size_t n, const double *src = nullptr) {
+        void *d = nullptr;
+        if (hipMalloc(&d, n * sizeof(double)) != hipSuccess) return nullptr;
+        v.push_back(d);
+        if (src && hipMemcpy(d, src, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return (double *)d;
+    }
+};
+thread_local std::string g_ops_error;
+int ops_fail(int code, const char *m) { g_ops_error = m; return code; }
+}  // namespace
+
+extern "C" {
+
+const char *gcm_ops_last_error(void) { return g_ops_error.c_str(); }
+
+int gcm_advect2d(int scheme, int axes, int finite, int width, int height, int nsteps, double dt,
+                 double dx0, double dx1, const double *V, const double *q_in, double *q_out) {
+    if (!V || !q_in || !q_out || width < 1 || height < 1 || nsteps < 0 || !(dx0 > 0) || !(dx1 > 0))
+        return ops_fail(GCM_ERR_ARG, "gcm_advect2d: bad argument");
+    if (scheme < GCM_ADV_UPWIND || scheme > GCM_ADV_MOMENTUM || axes < 1 || axes > 3)
+        return ops_fail(GCM_ERR_ARG, "gcm_advect2d: bad scheme/axes");
+    if (finite && (nsteps != 1 || axes == 3))
+        return ops_fail(GCM_ERR_ARG, "gcm_advect2d: finite (increment) output is per axis, one step");
+    if (gcm_device_count() < 1) return ops_fail(GCM_ERR_NODEVICE, "gcm_advect2d: no HIP device; no CPU fallback");
+    const size_t n = (size_t)width * height;
+    DevBuf mem;
+    double *v0 = mem.get(n, V), *v1 = mem.get(n, V + n);
+    double *qa = mem.get(n, q_in), *qb = mem.get(n);
+    double *m0 = nullptr, *m1 = nullptr;
+    if (scheme == GCM_ADV_MOMENTUM) { m0 = mem.get(n); m1 = mem.get(n); }
+    if (!v0 || !v1 || !qa || !qb || (scheme == GCM_ADV_MOMENTUM && (!m0 || !m1)))
+        return ops_fail(GCM_ERR_HIP, "gcm_advect2d: device allocation/upload failed");
+    const dim3 g((width + 63) / 64, (height + 3) / 4), b(64, 4);
+    const int kscheme = scheme == GCM_ADV_MOMENTUM ? 1 : scheme;   // momentum: fv upwind of V*p_edge
+    for (int s = 0; s < nsteps; ++s) {
+        const double *u0 = v0, *u1 = v1;
+        if (scheme == GCM_ADV_MOMENTUM) {
+            hipLaunchKernelGGL(momentum_kernel, g, b, 0, nullptr, m0, m1, v0, v1, qa, width, height);
+            u0 = m0; u1 = m1;
+        }
+        for (int axis = 0; axis < 2; ++axis) {
+            if (!(axes & (1 << axis))) continue;
+            AdvArgs a{axis == 0 ? u0 : u1, qa, qb, width, height, dt, axis == 0 ? dx0 : dx1,
+                      dt / (axis == 0 ? dx0 : dx1), 0.0, 1.0 * dx0 * dx1};
+            a.area = a.volume / a.dx;
+            if (axis == 0) { if (finite) launch_axis<0, true>(kscheme, a, g, b); else launch_axis<0, false>(kscheme, a, g, b); }
+            else { if (finite) launch_axis<1, true>(kscheme, a, g, b); else launch_axis<1, false>(kscheme, a, g, b); }
+            std::swap(qa, qb);
+        }
+    }
+    if (hipMemcpy(q_out, qa, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return ops_fail(GCM_ERR_HIP, "gcm_advect2d: kernel or copy-back failed");
+    return GCM_OK;
+}
+
+int gcm_pgf2d(int kind, int width, int height, double dt, double dx0, double dx1, const double *p,
+              const double *t, double *out2) {
+    if (!p || !out2 || width < 1 || height < 1 || kind < 0 || kind > 3 || (kind == 1 && !t))
+        return ops_fail(GCM_ERR_ARG, "gcm_pgf2d: bad argument");
+    if (gcm_device_count() < 1) return ops_fail(GCM_ERR_NODEVICE, "gcm_pgf2d: no HIP device; no CPU fallback");
+    const size_t n = (size_t)width * height;
+    DevBuf mem;
+    double tab[kExnerTabDoubles];
+    build_exner_table(tab);
+    double *dp = mem.get(n, p), *dt_ = t ? mem.get(n, t) : nullptr, *o = mem.get(2 * n),
+           *dtab = mem.get(kExnerTabDoubles, tab);
+    if (!dp || (t && !dt_) || !o || !dtab) return ops_fail(GCM_ERR_HIP, "gcm_pgf2d: device allocation failed");
+    hipLaunchKernelGGL(pgf_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(64, 4), 0, nullptr, o, o + n, dp,
+                       dt_, dtab, kind, width, height, dt, dx0, dx1);
+    if (hipMemcpy(out2, o, 2 * n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return ops_fail(GCM_ERR_HIP, "gcm_pgf2d: kernel or copy-back failed");
+    return GCM_OK;
+}
+
+}  // extern "C"

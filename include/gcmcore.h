@@ -163,6 +163,26 @@ int gcm_step_boundary(gcm_handle *h, double dt, void *stream);
 
 int gcm_sync(gcm_handle *h);
 
+/* Stand-alone 2-D operators of two_d.py on velocity stacks V[axis] (host arrays in/out; V is
+ * [2][H][W] with V[0] acting along array axis 0 = rows and dx0 = spatial_change[0], as
+ * two_d.py:16-22).  `axes` is a bit mask (1 = axis 0, 2 = axis 1, 3 = both, axis 0 first --
+ * the dimension split of corner_transport_2d / finite_volume_advection); `finite` = 1 returns
+ * the increment of one axis pass instead of the new field (the *_finite functions).          */
+typedef enum {
+    GCM_ADV_UPWIND = 0,    /* upwind_axis / corner_transport_2d           two_d.py:11-71            */
+    GCM_ADV_FV_UPWIND = 1, /* fv_advect_axis_upwind / finite_volume_advection  two_d.py:103-132,198-207 */
+    GCM_ADV_FV_PLAIN = 2,  /* fv_advect_axis_plain                        two_d.py:135-166          */
+    GCM_ADV_VANLEER = 3,   /* fv upwind + van_leer(calc_r)-limited centred flux (composition)        */
+    GCM_ADV_MOMENTUM = 4   /* advect_with_momentum: V * pressure_at_edge(p), then fv upwind  :277-292 */
+} gcm_adv_scheme;
+int gcm_advect2d(int scheme, int axes, int finite, int width, int height, int nsteps, double dt,
+                 double dx0, double dx1, const double *V, const double *q_in, double *q_out);
+/* kind 0: pgf_c_grid_axis gradients (two_d.py:210-220); 1: pgf_c_grid (needs t, :223-245);
+ * 2: pgf_templess (:248-261); 3: pressure_at_edge (:264-268).  out2 is [2][H][W].           */
+int gcm_pgf2d(int kind, int width, int height, double dt, double dx0, double dx1, const double *p,
+              const double *t, double *out2);
+const char *gcm_ops_last_error(void);
+
 /* Timing helper for bench.py: runs nsteps steps bracketed by HIP events on the
  * handle's stream; returns elapsed milliseconds in *ms and, in *kernel_ms_avg,
  * the mean duration of the dominant kernel's launches measured by per-launch
