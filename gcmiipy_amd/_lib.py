@@ -53,6 +53,7 @@ SYMBOLS = {
     "gcm_get_star": (C.c_int, [_H] + [C.c_void_p] * 5),
     "gcm_set_star": (C.c_int, [_H] + [C.c_void_p] * 5),
     "gcm_diag": (C.c_int, [_H, C.c_int, _dp]),
+    "gcm_energy": (C.c_int, [_H, _dp, C.c_int, _dp]),
     "gcm_halo_bytes": (C.c_size_t, [_H]),
     "gcm_halo_pack": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
     "gcm_halo_unpack": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),

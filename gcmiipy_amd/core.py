@@ -141,6 +141,13 @@ class Core:
         _check(lib.gcm_diag(self._h, kind, C.byref(out)), self._h)
         return out.value
 
+    def energy(self, area):
+        """(ke, ate, geo, total), no_limits_2_5d.calc_energy"""
+        a = as_f64(np.asarray(area, dtype=np.float64).reshape(-1), name="area")
+        out = (C.c_double * 4)()
+        _check(lib.gcm_energy(self._h, _tab(a), a.size, out), self._h)
+        return tuple(out)
+
     def time_steps(self, nsteps, dt, per_kernel=True):
         ms, kms = C.c_double(), C.c_double()
         _check(lib.gcm_time_steps(self._h, int(nsteps), float(dt), C.byref(ms),

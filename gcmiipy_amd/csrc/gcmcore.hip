@@ -589,6 +589,13 @@ int gcm_diag(gcm_handle *h, int kind, double *out) {
     return GCM_OK;
 }
 
+int gcm_energy(gcm_handle *h, const double *area, int area_len, double *out4) {
+    if (!h || !area || !out4 || area_len < 1) return GCM_ERR_ARG;
+    if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_energy: GCM_PE25D only");
+    int rc = pe25d_energy(h->pe, area, area_len, out4, &h->err);
+    return rc;
+}
+
 int gcm_time_steps(gcm_handle *h, int nsteps, double dt, double *ms, double *kernel_ms_avg) {
     if (!h || nsteps < 1 || !ms) return GCM_ERR_ARG;
     hipEvent_t e0, e1;

@@ -431,6 +431,55 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgs a) {
     if (k == 0) a.op[(long)j * W + i] = pn_c;
 }
 
+// ---------------------------------------------------------------- calc_energy (no_limits_2_5d.py:35-60)
+// thread per (j,i) column; out[4*block + {0,1,2}] = partial sums of ke, ate, geo
+__global__ __launch_bounds__(256) void pe_energy_kernel(PeArgs a, const double *area, int area_by_i,
+                                                        double *out) {
+    __shared__ double tab[kExnerTabDoubles];
+    __shared__ double red[3][4];
+    tab[threadIdx.x] = a.exner_tab[threadIdx.x];
+    __syncthreads();
+    const Idx ix{a.W, a.H, a.L, a.wrap};
+    const int W = a.W, L = a.L;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    double ke = 0.0, ate = 0.0, geo = 0.0;
+    if (i < W) {
+        const int iw = i == 0 ? W - 1 : i - 1;
+        const double pc = a.p[ix.r2(j) + i];
+        const double ar = area[area_by_i ? i : 0];   // geom.area (H,) broadcasts along the LAST axis (:49)
+        const long c3 = ix.r3(j), n3 = ix.r3(j - 1);
+        double depth = 0.0;
+        for (int k = 0; k < L; ++k) {
+            const long o = c3 + (long)k * W;
+            const double uc = (a.u[o + i] + a.u[o + iw]) * 0.5;                   // imh(u)
+            const double vc = (a.v[o + i] + a.v[n3 + (long)k * W + i]) * 0.5;     // jmh(v)
+            const double mag = sqrt(uc * uc + vc * vc);
+            const double tp = pc * a.sig[k] + a.ptop;
+            const double tt = a.t[o + i] * exner(tp, tab);
+            const double rho = tp / (kRd * tt);
+            const double gd = (pc * a.dsig[k]) / (rho * kG);
+            const double airmass = rho * gd * ar;
+            depth += gd;                                                          // cumsum over k
+            geo += depth * airmass * kG;
+            ke += mag * mag * .5 * airmass;
+            ate += tt * kCp * airmass;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        ke += __shfl_down(ke, o);
+        ate += __shfl_down(ate, o);
+        geo += __shfl_down(geo, o);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = ke; red[1][w] = ate; red[2][w] = geo; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double *o = out + 4 * ((long)blockIdx.y * gridDim.x + blockIdx.x);
+        for (int q = 0; q < 3; ++q) o[q] = red[q][0] + red[q][1] + red[q][2] + red[q][3];
+    }
+}
+
 // ---------------------------------------------------------------- layout transposes
 // host layout [k][j][i] (rows of THIS band only) <-> device [j][k][i]
 __global__ void pe_to_device_kernel(double *dst, const double *src, int W, int H, int L) {
@@ -800,6 +849,35 @@ int pe25d_halo(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s, std:
         *err = "hip: pe25d halo copy launch failed";
         return GCM_ERR_HIP;
     }
+    return GCM_OK;
+}
+
+int pe25d_energy(Pe25d *m, const double *area_host, int area_len, double out[4], std::string *err) {
+    if (!m->wrap) { *err = "gcm_energy: single band only"; return GCM_ERR_UNSUPPORTED; }
+    if (!(area_len == 1 || area_len == m->W)) {
+        *err = "gcm_energy: geom.area (H,) must broadcast against the last axis W (no_limits_2_5d.py:49): "
+               "needs H == W or H == 1";
+        return GCM_ERR_ARG;
+    }
+    const int gx = (m->W + 255) / 256, nb = gx * m->H;
+    double *d_area = nullptr, *d_out = nullptr;
+    if (hipMalloc((void **)&d_area, sizeof(double) * area_len) != hipSuccess ||
+        hipMalloc((void **)&d_out, sizeof(double) * 4 * nb) != hipSuccess ||
+        hipMemcpy(d_area, area_host, sizeof(double) * area_len, hipMemcpyHostToDevice) != hipSuccess) {
+        *err = "hip: gcm_energy allocation failed";
+        return GCM_ERR_HIP;
+    }
+    (void)hipDeviceSynchronize();
+    PeArgs a = make_args(m, m->cur_i, m->cur_i, 0.0);
+    hipLaunchKernelGGL(pe_energy_kernel, dim3(gx, m->H), dim3(256), 0, nullptr, a, d_area, area_len > 1 ? 1 : 0, d_out);
+    std::vector<double> part((size_t)4 * nb);
+    hipError_t e = hipMemcpy(part.data(), d_out, sizeof(double) * 4 * nb, hipMemcpyDeviceToHost);
+    (void)hipFree(d_area);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) { *err = "hip: gcm_energy kernel failed"; return GCM_ERR_HIP; }
+    double ke = 0, ate = 0, geo = 0;
+    for (int b = 0; b < nb; ++b) { ke += part[4 * b]; ate += part[4 * b + 1]; geo += part[4 * b + 2]; }
+    out[0] = ke; out[1] = ate; out[2] = geo; out[3] = ke + ate + geo;
     return GCM_OK;
 }
 

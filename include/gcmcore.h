@@ -148,6 +148,10 @@ typedef enum {
     GCM_DIAG_MIN_U = 4, GCM_DIAG_MAX_V = 5, GCM_DIAG_MIN_V = 6  /* STATS, no_limits_2_5d.py:85-88 */
 } gcm_diag_kind;
 int gcm_diag(gcm_handle *h, int kind, double *out);
+/* calc_energy(p,u,v,t,q,g,geom) -> out4 = (ke, ate, geo, total) in J, no_limits_2_5d.py:35-60
+ * (GCM_PE25D).  `area` is geom.area; the reference broadcasts its (H,) array against the LAST
+ * axis (:49), so area_len must be W (== H) or 1 -- reproduced, not fixed.                      */
+int gcm_energy(gcm_handle *h, const double *area, int area_len, double *out4);
 
 /* Latitude-band ghost rows (nranks > 1).  The library packs the rows a neighbour
  * needs into / unpacks them from caller-owned DEVICE buffers (e.g. torch tensors

@@ -30,3 +30,14 @@ def test_large_and_square_geometry_bit_exact():
     g = geometry.gen_square_geometry(6, 10, 3, 1000.0, 1200.0)
     for k in ("sige", "sigt", "sigb", "dsig", "sig", "dsigv", "dx_j", "dx_h", "dy", "ptop", "heightmap"):
         assert np.array_equal(np.asarray(getattr(g, k)), d["sq_6_10_3_" + k]), k
+
+
+def test_initial_conditions_bit_exact():
+    """no_limits_2_5d.gen_initial_conditions (host NumPy) vs arrays captured from the reference"""
+    from gcmiipy_amd import no_limits_2_5d as h
+    d = golden("g8_pe25d")
+    for (hh, w, l) in ((24, 36, 9), (8, 16, 4)):
+        g = geometry.gen_geometry(hh, w, l, sig_func=geometry.manabe_sig)
+        p, u, v, t, q, gr = h.gen_initial_conditions(g)
+        for k, x in zip(("p", "u", "v", "t", "q", "gt"), (p, u, v, t, q, gr.gt)):
+            assert np.array_equal(x, d["ic_%d_%d_%d_%s" % (hh, w, l, k)]), k

@@ -147,3 +147,42 @@ def test_filter_off_and_odd_width(g):
         g.Core(g._lib.PE25D, 9, 6, 2, geom=geom)
     c = g.Core(g._lib.PE25D, 9, 6, 2, geom=geom, filter=False)      # runs without the filter
     c.close()
+
+
+def test_harness_run_model_stats_and_energy(g):
+    """no_limits_2_5d.run_model at its main() size 8x8x3, dt = 1800 s: states after 1/3/10 steps,
+    STATS extrema and calc_energy vs values captured from the reference (G8)."""
+    from gcmiipy_amd import no_limits_2_5d as h
+    d = golden("g8_pe25d")
+    stats = {k: [] for k in ("u_max", "u_min", "v_max", "v_min", "ke")}
+    snaps = {}
+
+    def cb(p, u, v, t, q, _n=[0]):
+        _n[0] += 1
+        if _n[0] in (1, 3, 10):
+            snaps[_n[0]] = (p, u, v, t, q)
+
+    h.run_model(8, 8, 3, 1800.0, 10, cb, stats=stats)
+    for n, st in snaps.items():
+        for k, x in zip("puvtq", st):
+            y = d["harness%d_%s" % (n, k)]
+            scale = max(np.max(np.abs(y)), 1e-2 if k in "uv" else 0)
+            assert np.max(np.abs(x - y)) / scale < TOL, (n, k)
+    for k in ("u_max", "u_min", "v_max", "v_min"):
+        assert np.max(np.abs(np.asarray(stats[k]) - d["harness_stats_" + k])) < 1e-12, k
+    assert rel_err(np.asarray(stats["ke"])[:, 1:], d["harness_stats_ke"][:, 1:]) < 1e-12
+    ke, ke_ref = np.asarray(stats["ke"])[:, 0], d["harness_stats_ke"][:, 0]
+    assert np.max(np.abs(ke - ke_ref)) < 1e-9 * np.max(ke_ref)
+    with pytest.raises(ValueError, match="broadcast"):
+        from gcmiipy_amd import geometry
+        geom = geometry.gen_geometry(6, 8, 2)
+        h.calc_energy(*h.gen_initial_conditions(geom)[:5], None, geom)     # W != H: reference raises too
+
+
+def test_geography_energy(g):
+    from gcmiipy_amd import no_limits_2_5d as h
+    d = golden("g8_pe25d")
+    p, u, v, t, q, gr, geom = h.run_model(1, 16, 17, 1800.0, 3, None, stats={k: [] for k in
+                                          ("u_max", "u_min", "v_max", "v_min", "ke")}, bump=(0, 8, 1000))
+    _check((p, u, v, t, q), [d["bump3_" + k] for k in "puvtq"], "bump3 via run_model")
+    assert rel_err(np.asarray(h.calc_energy(p, u, v, t, q, gr, geom)), d["bump3_energy"]) < 1e-12
