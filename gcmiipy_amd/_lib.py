@@ -29,7 +29,7 @@ class Config(C.Structure):
         ("height", C.c_int32), ("layers", C.c_int32), ("tracer", C.c_int32),
         ("variant", C.c_int32), ("filter", C.c_int32), ("nranks", C.c_int32),
         ("rank", C.c_int32), ("global_height", C.c_int32), ("row0", C.c_int32),
-        ("device", C.c_int32), ("reserved0", C.c_int32),
+        ("device", C.c_int32), ("halo_steps", C.c_int32),
         ("dx", C.c_double), ("dy", C.c_double), ("ptop", C.c_double),
         ("dx_j", _dp), ("dx_h", _dp), ("sig", _dp), ("dsig", _dp), ("sigb", _dp),
         ("sigt", _dp), ("heightmap", _dp), ("stream", C.c_void_p),

@@ -9,6 +9,9 @@ to the two ring neighbours (point-to-point, no collective on the data path).
   2-D models (fused Matsuno kernel): ONE exchange per step.  The interior rows,
     which need no ghost data, are stepped on the compute stream while the exchange
     runs on a second stream; the four edge rows follow once the ghosts landed.
+    With `halo_steps = k > 1` the band carries 2k ghost rows and exchanges only every k steps
+    (deep halo: the rows still valid shrink by two per step) -- for small bands, where one
+    exchange costs more than a step.
   GCM_PE25D: TWO exchanges per step -- the current state before the predictor, the
     predicted state before the corrector (the corrector needs
     the neighbour's *predicted* rows, which cannot be recomputed from a 2-row halo).
@@ -48,6 +51,8 @@ class BandRunner:
         self.e, self.rank, self.n, self.dist = engine, rank, nranks, dist
         self.north = (rank - 1) % nranks
         self.south = (rank + 1) % nranks
+        self.k = getattr(engine, "steps_per_exchange", 1)
+        self.count = 0
 
     def exchange_start(self):
         d, e = self.dist, self.e
@@ -64,6 +69,17 @@ class BandRunner:
     def step(self, dt):
         if self.n == 1:
             self.e.step_all(dt)
+            return
+        if self.k > 1:                      # deep halo: exchange, then k purely local steps
+            if self.count % self.k == 0:
+                reqs = self.exchange_start()
+                for r in reqs:
+                    r.wait()
+                self.e.comm_end()
+                self.e.unpack(0)
+                self.e.unpack(1)
+            self.e.step_all(dt)
+            self.count += 1
             return
         for phase in range(self.e.phases):
             reqs = self.exchange_start()
@@ -88,6 +104,7 @@ class HipBandEngine:
         self.c, self.torch = core, torch
         self.pe = core.model == _lib.PE25D
         self.phases = 2 if self.pe else 1
+        self.steps_per_exchange = getattr(core, "halo_steps", 1)
         nbytes = core.halo_bytes()
         dev = torch.device("cuda", torch.cuda.current_device())
         mk = lambda: torch.empty(nbytes // 8, dtype=torch.float64, device=dev)

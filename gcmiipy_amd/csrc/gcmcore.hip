@@ -33,6 +33,8 @@ struct gcm_handle {
     double *geo = nullptr, *irho = nullptr, *sst = nullptr, *qtmp = nullptr;
     bool has[GCM_NFIELDS] = {};
     double *exner_tab = nullptr;
+    int G = kGhost;          // ghost rows per side = 2 * steps between exchanges (2-D bands)
+    int since_exchange = 0;  // steps taken on the current ghost rows
     bool star_valid = false;
     int variant = GCM_VARIANT_FUSED;
     int rows_per_band = 32;
@@ -68,12 +70,12 @@ static int fail(gcm_handle *h, int code, const std::string &msg) {
 }
 
 static int alloc_field(gcm_handle *h, double **p) {
-    const size_t n = (size_t)(h->H + 2 * kGhost) * h->W;
+    const size_t n = (size_t)(h->H + 2 * h->G) * h->W;
     void *d = nullptr;
     HIPCHK(h, hipMalloc(&d, n * sizeof(double)));
     HIPCHK(h, hipMemsetAsync(d, 0, n * sizeof(double), h->stream));
     h->allocs.push_back(d);
-    *p = (double *)d + (size_t)kGhost * h->W;
+    *p = (double *)d + (size_t)h->G * h->W;
     return GCM_OK;
 }
 
@@ -119,8 +121,11 @@ int gcm_create(const gcm_config *cfg, gcm_handle **out) {
         return fail(nullptr, GCM_ERR_ARG, "gcm_create: width/height/layers must be >= 1");
     if (cfg->nranks < 1 || cfg->rank < 0 || cfg->rank >= cfg->nranks)
         return fail(nullptr, GCM_ERR_ARG, "gcm_create: bad rank/nranks");
-    if (cfg->nranks > 1 && cfg->height < kGhost)
-        return fail(nullptr, GCM_ERR_ARG, "gcm_create: a latitude band needs >= 2 rows");
+    const int hsteps = cfg->halo_steps < 1 ? 1 : cfg->halo_steps;
+    if (cfg->nranks > 1 && cfg->height < kGhost * hsteps)
+        return fail(nullptr, GCM_ERR_ARG, "gcm_create: a latitude band needs >= 2 * halo_steps rows");
+    if (hsteps > 1 && (cfg->nranks == 1 || (cfg->model != GCM_SW2D && cfg->model != GCM_SW2D_TEMP)))
+        return fail(nullptr, GCM_ERR_ARG, "gcm_create: halo_steps > 1 needs a 2-D latitude band");
     if (gcm_device_count() < 1)
         return fail(nullptr, GCM_ERR_NODEVICE,
                     "gcm_create: no HIP device visible; libgcmcore has no CPU fallback");
@@ -130,6 +135,7 @@ int gcm_create(const gcm_config *cfg, gcm_handle **out) {
     h->H = cfg->height;
     h->L = cfg->layers;
     h->wrap = cfg->nranks == 1;
+    h->G = kGhost * hsteps;
     h->stream = (hipStream_t)cfg->stream;
     int rc = GCM_OK;
     auto bail = [&](int code, const std::string &m) {
@@ -405,12 +411,16 @@ int gcm_step(gcm_handle *h, int nsteps, double dt) {
         }
         return GCM_OK;
     }
-    if (!h->wrap && nsteps > 1)
+    if (!h->wrap && h->since_exchange + nsteps > h->G / kGhost)
         return fail(h, GCM_ERR_STATE,
-                    "gcm_step: a latitude band needs a ghost-row exchange between steps");
+                    "gcm_step: a latitude band needs a ghost-row exchange every halo_steps steps");
     for (int n = 0; n < nsteps; ++n) {
-        step_rows(h, dt, 0, h->H, h->stream);
+        // bands: each step consumes two ghost rows per side; the rows still valid shrink towards
+        // the interior until the next exchange (communication-avoiding deep halo)
+        const int e = h->wrap ? 0 : h->G - kGhost * (h->since_exchange + 1);
+        step_rows(h, dt, -e, h->H + e, h->stream);
         swap_state(h);
+        if (!h->wrap) ++h->since_exchange;
     }
     h->star_valid = false;
     HIPCHK(h, hipGetLastError());
@@ -421,6 +431,7 @@ int gcm_step_interior(gcm_handle *h, double dt, void *stream) {
     if (!h) return GCM_ERR_ARG;
     if (h->pe) return pe25d_step_part(h->pe, 0, dt, (hipStream_t)stream, &h->err);
     if (h->wrap) return fail(h, GCM_ERR_STATE, "step_interior: handle is not a latitude band");
+    if (h->G != kGhost) return fail(h, GCM_ERR_STATE, "step_interior: halo_steps > 1 steps through gcm_step");
     step_rows(h, dt, kGhost, h->H - kGhost, (hipStream_t)stream);
     HIPCHK(h, hipGetLastError());
     return GCM_OK;
@@ -467,7 +478,7 @@ size_t gcm_halo_bytes(const gcm_handle *h) {
     if (h->pe) return pe25d_halo_bytes(h->pe);
     int nf = 0;
     for (int f = 0; f < GCM_NFIELDS; ++f) nf += h->has[f];
-    return (size_t)nf * kGhost * h->W * sizeof(double);
+    return (size_t)nf * h->G * h->W * sizeof(double);
 }
 
 // side 0: rows [0, 2) -> buffer (they become the north neighbour's south ghost rows)
@@ -476,11 +487,11 @@ int gcm_halo_pack(gcm_handle *h, int side, void *dev_buf, void *stream) {
     if (!h || !dev_buf || (side != 0 && side != 1)) return GCM_ERR_ARG;
     if (h->pe) return pe25d_halo(h->pe, true, side, dev_buf, (hipStream_t)stream, &h->err);
     double *b = (double *)dev_buf;
-    const size_t n = (size_t)kGhost * h->W;
+    const size_t n = (size_t)h->G * h->W;
     for (int f = 0; f < GCM_NFIELDS; ++f) {
         if (!h->has[f]) continue;
-        const double *src = side == 0 ? h->cur[f] : h->cur[f] + (size_t)(h->H - kGhost) * h->W;
-        launch_copy_rows(b, src, h->W, kGhost, (hipStream_t)stream);
+        const double *src = side == 0 ? h->cur[f] : h->cur[f] + (size_t)(h->H - h->G) * h->W;
+        launch_copy_rows(b, src, h->W, h->G, (hipStream_t)stream);
         b += n;
     }
     HIPCHK(h, hipGetLastError());
@@ -492,11 +503,12 @@ int gcm_halo_unpack(gcm_handle *h, int side, const void *dev_buf, void *stream) 
     if (!h || !dev_buf || (side != 0 && side != 1)) return GCM_ERR_ARG;
     if (h->pe) return pe25d_halo(h->pe, false, side, (void *)dev_buf, (hipStream_t)stream, &h->err);
     const double *b = (const double *)dev_buf;
-    const size_t n = (size_t)kGhost * h->W;
+    const size_t n = (size_t)h->G * h->W;
+    h->since_exchange = 0;
     for (int f = 0; f < GCM_NFIELDS; ++f) {
         if (!h->has[f]) continue;
         double *dst = side == 0 ? h->cur[f] - n : h->cur[f] + (size_t)h->H * h->W;
-        launch_copy_rows(dst, b, h->W, kGhost, (hipStream_t)stream);
+        launch_copy_rows(dst, b, h->W, h->G, (hipStream_t)stream);
         b += n;
     }
     HIPCHK(h, hipGetLastError());

@@ -80,14 +80,15 @@ typedef struct {
     int32_t filter;        /* GCM_PE25D: 1 = apply low_pass.arakawa_1977 (low_pass.py:41-78)     */
     /* Latitude-band decomposition.  nranks == 1: the handle owns the whole grid
      * and np.roll's pole-to-pole periodicity along j is done by index arithmetic.  nranks > 1:
-     * rows [row0, row0+height) of a global_height-row grid; the two ghost rows on either side
+     * rows [row0, row0+height) of a global_height-row grid; the ghost rows on either side
      * are filled by the caller between steps through gcm_halo_* (RCCL ring incl. the wrap).    */
     int32_t nranks;
     int32_t rank;
     int32_t global_height;
     int32_t row0;
     int32_t device;        /* HIP device ordinal; -1 = current                                   */
-    int32_t reserved0;
+    int32_t halo_steps;    /* 2-D bands: Matsuno steps per ghost-row exchange (ghost depth = 2 *
+                              halo_steps rows per side, deep-halo communication avoiding); 0/1 = 1 */
     double dx;             /* scalar grid spacing in metres (2-D models: both axes)              */
     double dy;             /* GCM_PE25D: geom.dy                            geometry.py:138      */
     double ptop;           /* GCM_PE25D: geom.ptop in Pa                    geometry.py:147      */

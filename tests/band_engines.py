@@ -15,8 +15,10 @@ class NumpyBand2D:
     """GCM_SW2D / GCM_SW2D_TEMP(+van Leer tracer) on one band; state: dict name -> (H+4, W)."""
     phases = 1
 
-    def __init__(self, fields, dx, temp, log=None):
-        self.f = {k: np.pad(v, ((G, G), (0, 0))) for k, v in fields.items()}
+    def __init__(self, fields, dx, temp, log=None, halo_steps=1):
+        self.G = G * halo_steps                 # deep halo: 2 ghost rows per local step
+        self.steps_per_exchange = halo_steps
+        self.f = {k: np.pad(v, ((self.G, self.G), (0, 0))) for k, v in fields.items()}
         self.names = sorted(fields)
         self.H = next(iter(fields.values())).shape[0]
         self.dx, self.temp = dx, temp
@@ -33,17 +35,17 @@ class NumpyBand2D:
         return dict(u=u, v=v, p=p)
 
     def send_buffer(self, side):
-        rows = slice(G, 2 * G) if side == 0 else slice(self.H, self.H + G)
+        rows = slice(self.G, 2 * self.G) if side == 0 else slice(self.H, self.H + self.G)
         return torch.from_numpy(np.concatenate([self.f[k][rows].ravel() for k in self.names]))
 
     def recv_buffer(self, side):
-        n = sum(self.f[k][:G].size for k in self.names)
+        n = sum(self.f[k][:self.G].size for k in self.names)
         self.rb[side] = torch.empty(n, dtype=torch.float64)
         return self.rb[side]
 
     def unpack(self, side):
         buf = self.rb[side].numpy()
-        rows = slice(0, G) if side == 0 else slice(self.H + G, self.H + 2 * G)
+        rows = slice(0, self.G) if side == 0 else slice(self.H + self.G, self.H + 2 * self.G)
         off = 0
         for k in self.names:
             n = self.f[k][rows].size
@@ -72,10 +74,13 @@ class NumpyBand2D:
             self.f[k][G:self.H + G] = new[k][G:self.H + G]
 
     def step_all(self, dt):
-        raise AssertionError("not used with nranks > 1")
+        # deep-halo local step: the whole extended band; np.roll's wrap pollutes two more ghost
+        # rows per step, never the interior within `halo_steps` steps
+        assert self.steps_per_exchange > 1
+        self.f.update(self._full_step(dt))
 
     def interior_state(self):
-        return {k: v[G:self.H + G].copy() for k, v in self.f.items()}
+        return {k: v[self.G:self.H + self.G].copy() for k, v in self.f.items()}
 
 
 def band_geom(global_geom, row0, nrows):

@@ -37,7 +37,7 @@ def _ic2d(shape, temp):
     return f
 
 
-def _worker_2d(rank, world, port, shape, temp, steps, outdir):
+def _worker_2d(rank, world, port, shape, temp, steps, outdir, halo_steps=1):
     from band_engines import NumpyBand2D
     from gcmiipy_amd.bands import BandRunner, split_rows
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -45,12 +45,15 @@ def _worker_2d(rank, world, port, shape, temp, steps, outdir):
     full = _ic2d(shape, temp)
     row0, n = split_rows(shape[0], world)[rank]
     log = []
-    eng = NumpyBand2D({k: v[row0:row0 + n] for k, v in full.items()}, 300e3, temp, log)
+    eng = NumpyBand2D({k: v[row0:row0 + n] for k, v in full.items()}, 300e3, temp, log, halo_steps)
     runner = BandRunner(eng, rank, world, dist)
     for _ in range(steps):
         runner.step(300.0)
-    # the runner must start the exchange, then the interior, then wait/unpack, then the boundary
-    assert log[:6] == ["comm_begin", "interior", "comm_end", "unpack0", "unpack1", "boundary"], log[:6]
+    if halo_steps == 1:
+        # the runner must start the exchange, then the interior, then wait/unpack, then the boundary
+        assert log[:6] == ["comm_begin", "interior", "comm_end", "unpack0", "unpack1", "boundary"], log[:6]
+    else:
+        assert log.count("unpack0") == -(-steps // halo_steps)      # one exchange per halo_steps steps
     np.savez(os.path.join(outdir, "r%d.npz" % rank), **eng.interior_state())
     dist.barrier()
     dist.destroy_process_group()
@@ -118,6 +121,21 @@ def test_banded_2d_equals_single_domain(tmp_path, world, temp):
     for k in f:
         got = np.concatenate([pp[k] for pp in parts], axis=0)
         assert np.array_equal(got, f[k]), k
+
+
+def test_banded_2d_deep_halo(tmp_path):
+    """halo_steps = 2: exchange every second step, 5 steps (last window partial)"""
+    from oracle import sw2d
+    shape, steps, world = (18, 24), 5, 3
+    mp.spawn(_worker_2d, args=(world, _free_port(), shape, False, steps, str(tmp_path), 2), nprocs=world,
+             join=True)
+    f = _ic2d(shape, False)
+    for _ in range(steps):
+        u, v, p = sw2d.matsumo_scheme(f["u"], f["v"], f["p"], 300e3, 300.0)
+        f = dict(u=u, v=v, p=p)
+    parts = [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(world)]
+    for k in f:
+        assert np.array_equal(np.concatenate([pp[k] for pp in parts], axis=0), f[k]), k
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -86,6 +86,39 @@ def test_bands_in_process_2d(variant, nb):
         assert rel_err(a, b) < 1e-13, (k, rel_err(a, b))
 
 
+@pytest.mark.parametrize("variant", ["fused", "staged"])
+def test_deep_halo_in_process_2d(variant):
+    """halo_steps = 3: 6 ghost rows per side, one exchange per 3 steps"""
+    import torch
+    import gcmiipy_amd as g
+    from gcmiipy_amd.bands import split_rows
+    H, W, k, nb = 40, 130, 3, 3
+    var = g._lib.VARIANT_FUSED if variant == "fused" else g._lib.VARIANT_STAGED
+    f = _ic2d((H, W))
+    ref = g.Core(g._lib.SW2D_TEMP, W, H, dx=300e3, tracer=g._lib.TRACER_VANLEER, variant=var)
+    ref.set_state(**f)
+    ref.step(2 * k, 300.0)
+    want = ref.get_state()
+    ref.close()
+    cores = []
+    for r, (row0, n) in enumerate(split_rows(H, nb)):
+        c = g.Core(g._lib.SW2D_TEMP, W, n, dx=300e3, tracer=g._lib.TRACER_VANLEER, variant=var,
+                   nranks=nb, rank=r, global_height=H, row0=row0, halo_steps=k)
+        c.set_state(**{kk: v[row0:row0 + n] for kk, v in f.items()})
+        cores.append(c)
+    for _ in range(2):
+        _exchange(cores, torch)
+        for c in cores:
+            c.step(k, 300.0)
+        with pytest.raises(g.GcmError):
+            cores[0].step(1, 300.0)          # ghost rows used up: an exchange is due
+    got = [np.concatenate(x, axis=0) for x in zip(*[c.get_state() for c in cores])]
+    for c in cores:
+        c.close()
+    for kk, a, b in zip("puvtq", got, want):
+        assert rel_err(a, b) < 1e-13, (kk, rel_err(a, b))
+
+
 @pytest.mark.parametrize("nb", [2, 3])
 def test_bands_in_process_pe25d(nb):
     import torch
@@ -142,12 +175,13 @@ def _worker(rank, world, port, model, outdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    if model == "c3":
-        H, W, steps, dt = 40, 130, 3, 300.0
+    if model in ("c3", "c3deep"):
+        H, W, steps, dt = 40, 130, 3 if model == "c3" else 4, 300.0
         f = _ic2d((H, W))
         row0, n = split_rows(H, world)[rank]
         c = g.Core(g._lib.SW2D_TEMP, W, n, dx=300e3, tracer=g._lib.TRACER_VANLEER, nranks=world, rank=rank,
-                   global_height=H, row0=row0, stream=torch.cuda.current_stream().cuda_stream)
+                   global_height=H, row0=row0, stream=torch.cuda.current_stream().cuda_stream,
+                   halo_steps=1 if model == "c3" else 2)
         c.set_state(**{k: v[row0:row0 + n] for k, v in f.items()})
     else:
         H, W, L, steps, dt = 14, 20, 5, 2, 120.0
@@ -169,7 +203,7 @@ def _worker(rank, world, port, model, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model", ["c3", "pe"])
+@pytest.mark.parametrize("model", ["c3", "c3deep", "pe"])
 def test_band_runner_two_processes_one_gpu(tmp_path, model):
     import torch.multiprocessing as mp
     import gcmiipy_amd as g
@@ -177,11 +211,11 @@ def test_band_runner_two_processes_one_gpu(tmp_path, model):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), model, str(tmp_path)), nprocs=world, join=True)
     parts = [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(world)]
-    if model == "c3":
+    if model in ("c3", "c3deep"):
         H, W = 40, 130
         ref = g.Core(g._lib.SW2D_TEMP, W, H, dx=300e3, tracer=g._lib.TRACER_VANLEER)
         ref.set_state(**_ic2d((H, W)))
-        ref.step(3, 300.0)
+        ref.step(3 if model == "c3" else 4, 300.0)
     else:
         H, W, L = 14, 20, 5
         geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
