@@ -53,6 +53,7 @@ class BandRunner:
         self.south = (rank + 1) % nranks
         self.k = getattr(engine, "steps_per_exchange", 1)
         self.count = 0
+        self._ops = None
 
     def exchange_start(self):
         d, e = self.dist, self.e
@@ -61,10 +62,13 @@ class BandRunner:
         # order matters when both neighbours are the same peer (N == 2): sends go
         # north-edge first, receives take the south ghost first (it is the peer's
         # north edge), so the i-th send pairs with the peer's i-th receive.
-        ops = [d.P2POp(d.isend, sn, self.north), d.P2POp(d.isend, ss, self.south),
-               d.P2POp(d.irecv, e.recv_buffer(1), self.south),
-               d.P2POp(d.irecv, e.recv_buffer(0), self.north)]
-        return d.batch_isend_irecv(ops)
+        rs, rn = e.recv_buffer(1), e.recv_buffer(0)
+        if self._ops is None or self._ops[0] != (id(sn), id(ss), id(rs), id(rn)):
+            # the buffers of a GPU engine are persistent: build the P2P descriptors once
+            self._ops = ((id(sn), id(ss), id(rs), id(rn)),
+                         [d.P2POp(d.isend, sn, self.north), d.P2POp(d.isend, ss, self.south),
+                          d.P2POp(d.irecv, rs, self.south), d.P2POp(d.irecv, rn, self.north)])
+        return d.batch_isend_irecv(self._ops[1])
 
     def step(self, dt):
         if self.n == 1:

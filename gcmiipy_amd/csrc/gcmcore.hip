@@ -488,12 +488,15 @@ int gcm_halo_pack(gcm_handle *h, int side, void *dev_buf, void *stream) {
     if (h->pe) return pe25d_halo(h->pe, true, side, dev_buf, (hipStream_t)stream, &h->err);
     double *b = (double *)dev_buf;
     const size_t n = (size_t)h->G * h->W;
+    SegCopy c{};
     for (int f = 0; f < GCM_NFIELDS; ++f) {
         if (!h->has[f]) continue;
-        const double *src = side == 0 ? h->cur[f] : h->cur[f] + (size_t)(h->H - h->G) * h->W;
-        launch_copy_rows(b, src, h->W, h->G, (hipStream_t)stream);
+        c.src[c.nseg] = side == 0 ? h->cur[f] : h->cur[f] + (size_t)(h->H - h->G) * h->W;
+        c.dst[c.nseg] = b;
+        c.n[c.nseg++] = (long)n;
         b += n;
     }
+    launch_seg_copy(c, (hipStream_t)stream);
     HIPCHK(h, hipGetLastError());
     return GCM_OK;
 }
@@ -505,12 +508,15 @@ int gcm_halo_unpack(gcm_handle *h, int side, const void *dev_buf, void *stream) 
     const double *b = (const double *)dev_buf;
     const size_t n = (size_t)h->G * h->W;
     h->since_exchange = 0;
+    SegCopy c{};
     for (int f = 0; f < GCM_NFIELDS; ++f) {
         if (!h->has[f]) continue;
-        double *dst = side == 0 ? h->cur[f] - n : h->cur[f] + (size_t)h->H * h->W;
-        launch_copy_rows(dst, b, h->W, h->G, (hipStream_t)stream);
+        c.dst[c.nseg] = side == 0 ? h->cur[f] - n : h->cur[f] + (size_t)h->H * h->W;
+        c.src[c.nseg] = b;
+        c.n[c.nseg++] = (long)n;
         b += n;
     }
+    launch_seg_copy(c, (hipStream_t)stream);
     HIPCHK(h, hipGetLastError());
     return GCM_OK;
 }

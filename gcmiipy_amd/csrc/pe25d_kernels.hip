@@ -19,6 +19,7 @@
 #include <cstring>
 
 #include "gcm_math.h"
+#include "sw2d_kernels.h"
 
 namespace gcm {
 
@@ -825,26 +826,22 @@ size_t pe25d_halo_bytes(const Pe25d *m) {
     return sizeof(double) * (size_t)kGhost * m->W * (1 + 4 * (size_t)m->L);
 }
 
-__global__ void pe_copy_kernel(double *dst, const double *src, long n) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        dst[i] = src[i];
-}
-
 int pe25d_halo(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s, std::string *err) {
     const int set = m->star_valid ? 2 : m->cur_i;
     double *b = (double *)dev_buf;
+    SegCopy c{};
     for (int f = 0; f < GCM_NFIELDS; ++f) {
         const size_t per_row = (size_t)m->W * (f == GCM_P ? 1 : m->L);
         const long n = (long)(kGhost * per_row);
         double *base = m->st[set][f];
         double *edge = side == 0 ? base : base + (size_t)(m->H - kGhost) * per_row;
         double *ghost = side == 0 ? base - (size_t)kGhost * per_row : base + (size_t)m->H * per_row;
-        int blocks = (int)((n + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        if (pack) hipLaunchKernelGGL(pe_copy_kernel, dim3(blocks), dim3(256), 0, s, b, edge, n);
-        else hipLaunchKernelGGL(pe_copy_kernel, dim3(blocks), dim3(256), 0, s, ghost, b, n);
+        c.src[c.nseg] = pack ? edge : b;
+        c.dst[c.nseg] = pack ? b : ghost;
+        c.n[c.nseg++] = n;
         b += n;
     }
+    launch_seg_copy(c, s);
     if (hipGetLastError() != hipSuccess) {
         *err = "hip: pe25d halo copy launch failed";
         return GCM_ERR_HIP;

@@ -45,4 +45,13 @@ void build_exner_table(double *tab);
 // ghost rows for a single band that is stepped with wrap_j == 0 (tests) and halo pack/unpack
 void launch_copy_rows(double *dst, const double *src, int W, int nrows, hipStream_t s);
 
+// up to 5 contiguous segments copied by ONE launch (ghost-row pack / unpack of all fields)
+struct SegCopy {
+    double *dst[5];
+    const double *src[5];
+    long n[5];
+    int nseg;
+};
+void launch_seg_copy(const SegCopy &c, hipStream_t s);
+
 }  // namespace gcm

@@ -417,4 +417,23 @@ void launch_copy_rows(double *dst, const double *src, int W, int nrows, hipStrea
     hipLaunchKernelGGL(copy_rows_kernel, dim3(blocks), dim3(256), 0, s, dst, src, n);
 }
 
+__global__ void seg_copy_kernel(SegCopy c) {
+    const int seg = blockIdx.y;
+    if (seg >= c.nseg) return;
+    const long n = c.n[seg];
+    const double *src = c.src[seg];
+    double *dst = c.dst[seg];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+}
+
+void launch_seg_copy(const SegCopy &c, hipStream_t s) {
+    long mx = 0;
+    for (int k = 0; k < c.nseg; ++k) mx = c.n[k] > mx ? c.n[k] : mx;
+    if (mx <= 0 || c.nseg <= 0) return;
+    int blocks = (int)((mx + 255) / 256);
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(seg_copy_kernel, dim3(blocks, c.nseg), dim3(256), 0, s, c);
+}
+
 }  // namespace gcm
