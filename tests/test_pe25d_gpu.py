@@ -186,3 +186,26 @@ def test_geography_energy(g):
                                           ("u_max", "u_min", "v_max", "v_min", "ke")}, bump=(0, 8, 1000))
     _check((p, u, v, t, q), [d["bump3_" + k] for k in "puvtq"], "bump3 via run_model")
     assert rel_err(np.asarray(h.calc_energy(p, u, v, t, q, gr, geom)), d["bump3_energy"]) < 1e-12
+
+
+def test_checkpoint_resume_bit_exact(g, tmp_path):
+    """save after 2 steps, restore into a fresh Core, 2 more steps == 4 uninterrupted steps"""
+    from gcmiipy_amd import geometry, checkpoint
+    d = golden("g8_pe25d")
+    geom = geometry.gen_geometry(24, 36, 9, sig_func=geometry.manabe_sig)
+    ic = [d["dense_%s0" % k] for k in "puvtq"]
+    a = g.Core(g._lib.PE25D, 36, 24, 9, geom=geom)
+    a.set_state(*ic)
+    a.step(2, 300.0)
+    path = str(tmp_path / "ck.npz")
+    checkpoint.save(path, a, step=2, time=600.0, geom=geom, note=np.asarray([1.0]))
+    a.step(2, 300.0)
+    want = a.get_state()
+    a.close()
+    b, ck = checkpoint.restore(path)
+    assert ck["step"] == 2 and ck["time"] == 600.0 and ck["model"] == "PE25D"
+    assert np.array_equal(ck["geom"].dx_j, geom.dx_j)
+    b.step(2, 300.0)
+    for x, y in zip(b.get_state(), want):
+        assert np.array_equal(x, y)
+    b.close()
