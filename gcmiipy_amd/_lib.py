@@ -67,7 +67,30 @@ SYMBOLS = {
 }
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, but requested by
+    file name).  If the system runtime is loaded first and torch later, the process ends up with
+    TWO HIP runtimes and torch.cuda fails with "No HIP GPUs are available".  Loading torch's copy
+    first (without importing torch) makes libgcmcore.so and torch share one runtime in either
+    import order.  GCMCORE_SYSTEM_HIP=1 skips this."""
+    if os.environ.get("GCMCORE_SYSTEM_HIP"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
 def _load():
+    _preload_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "gcmiipy_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; "

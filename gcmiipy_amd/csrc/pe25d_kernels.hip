@@ -337,20 +337,27 @@ __global__ __launch_bounds__(256) void pe_pgf_filter_kernel(PeArgs a) {
 }
 
 // ---------------------------------------------------------------- K4: update
+// One thread per (j, i) column marching up the levels: the k-1 / k / k+1 values of the stage
+// winds, theta, q and sigma-dot rotate through registers, so only the horizontal neighbours
+// are loaded per level.  Tiles (row, 256-column block) are dealt to the 8 XCDs in contiguous
+// runs of rows (as sw2d_fused_kernel does): the blocks resident on one XCD work on adjacent
+// rows at about the same level, so the j+-1 re-reads hit that XCD's L2.
 __global__ __launch_bounds__(256) void pe_update_kernel(PeArgs a) {
     const Idx ix{a.W, a.H, a.L, a.wrap};
     const int W = a.W, L = a.L;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int k = blockIdx.y;
-    const int j = a.j0 + blockIdx.z;
+    const int iblocks = (W + 255) / 256;
+    const int per_xcd = gridDim.x / 8;
+    const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const int jrel = tile / iblocks;
+    if (jrel >= a.j1 - a.j0) return;                          // padding tiles
+    const int j = a.j0 + jrel;
+    const int i = (tile - jrel * iblocks) * 256 + threadIdx.x;
     if (i >= W) return;
     const int iw = i == 0 ? W - 1 : i - 1, ie = i + 1 == W ? 0 : i + 1;
-    const int km = k == 0 ? L - 1 : k - 1, kp = k + 1 == L ? 0 : k + 1;
     const int jg = wrapi(a.row0 + j, a.Hg);
     const double inv_dxj = a.inv_dxj[jg], inv_dxh = a.inv_dxh[jg], inv_dy = a.inv_dy, dt = a.dt;
     const long rc = ix.r3(j), rn = ix.r3(j - 1), rs = ix.r3(j + 1);
-    const long kc = (long)k * W, kmo = (long)km * W, kpo = (long)kp * W;
-    // surface pressure of the stage state on rows j-1 .. j+2
+    // surface pressure of the stage state on rows j-1 .. j+2 (level independent)
     const double *spr = a.sp;
     const long p_n = ix.r2(j - 1), p_c = ix.r2(j), p_s = ix.r2(j + 1), p_ss = ix.r2(j + 2);
     const double sp_c = spr[p_c + i], sp_e = spr[p_c + ie];
@@ -359,77 +366,97 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgs a) {
     const double jph_c = (sp_c + sp_s) * 0.5, jph_ce = (sp_e + sp_se) * 0.5;     // jph(sp) at (j,i),(j,i+1)
     const double jph_n = (sp_n + sp_c) * 0.5, jph_ne = (sp_ne + sp_e) * 0.5;     // at (j-1,i),(j-1,i+1)
     const double jph_s = (sp_s + sp_ss) * 0.5;                                   // at (j+1,i)
-    // stage winds
-    const double su_c = a.su[rc + kc + i], su_w = a.su[rc + kc + iw], su_e = a.su[rc + kc + ie];
-    const double su_n = a.su[rn + kc + i], su_s = a.su[rs + kc + i];
-    const double sv_c = a.sv[rc + kc + i], sv_w = a.sv[rc + kc + iw], sv_e = a.sv[rc + kc + ie];
-    const double sv_n = a.sv[rn + kc + i], sv_ne = a.sv[rn + kc + ie], sv_s = a.sv[rs + kc + i];
-    // mass fluxes: spu filtered (K1); spv = sv * jph(sp), dynamics.py:20-22
-    const double spu_c = a.spu[rc + kc + i], spu_w = a.spu[rc + kc + iw], spu_e = a.spu[rc + kc + ie];
-    const double spu_s = a.spu[rs + kc + i], spu_sw = a.spu[rs + kc + iw];
-    const double spv_c = sv_c * jph_c, spv_e = sv_e * jph_ce;
-    const double spv_n = sv_n * jph_n, spv_ne = sv_ne * jph_ne;
-    const double spv_s = sv_s * jph_s;
-    // ---- advec_m_pu, dynamics.py:55-108
-    const double puum = ((su_c + su_w) * 0.5) * ((spu_c + spu_w) * 0.5);
-    const double puup = ((su_e + su_c) * 0.5) * ((spu_e + spu_c) * 0.5);
-    const double puvp = ((spv_c + spv_e) * 0.5) * ((su_c + su_s) * 0.5);
-    const double puvm = ((spv_n + spv_ne) * 0.5) * ((su_n + su_c) * 0.5);
-    const double pvvm = ((sv_c + sv_n) * 0.5) * ((spv_c + spv_n) * 0.5);
-    const double pvvp = ((sv_s + sv_c) * 0.5) * ((spv_s + spv_c) * 0.5);
-    const double pvup = ((sv_c + sv_e) * 0.5) * ((spu_c + spu_s) * 0.5);
-    const double pvum = ((sv_w + sv_c) * 0.5) * ((spu_w + spu_sw) * 0.5);
-    const double dut = (puum - puup) * inv_dxj + (puvm - puvp) * inv_dy + 0.0;
-    const double dvt = (pvvm - pvvp) * inv_dy + (pvum - pvup) * inv_dxh + 0.0;
-    // ---- pgf v-part, dynamics.py:160,167-169 (the u-part went through K3)
-    const double sg = a.sig[k];
-    const double phi_c = a.phi[rc + kc + i], phi_s = a.phi[rs + kc + i];
-    const double rho_c = a.rho[rc + kc + i], rho_s = a.rho[rs + kc + i];
-    const double phiv = jph_c * ((phi_s - phi_c) * inv_dy);
-    const double pgv = ((sg * sp_c + sg * sp_s) * 0.5) * rcp((rho_c + rho_s) * 0.5) * ((sp_s - sp_c) * inv_dy);
-    // ---- vertical advection, dynamics.py:49-52 with iph(sd), jph(sd), sd
-    const double sd_c = a.sd[rc + kc + i], sd_e = a.sd[rc + kc + ie], sd_s = a.sd[rs + kc + i];
-    const double sd_cp = a.sd[rc + kpo + i], sd_ep = a.sd[rc + kpo + ie], sd_sp = a.sd[rs + kpo + i];
-    const double inv_ds = a.inv_dsig[k];
-    const double su_m = a.su[rc + kmo + i], su_p = a.su[rc + kpo + i];
-    const double sv_m = a.sv[rc + kmo + i], sv_p = a.sv[rc + kpo + i];
-    const double st_c = a.st[rc + kc + i], st_m = a.st[rc + kmo + i], st_p = a.st[rc + kpo + i];
-    const double sq_c = a.sq[rc + kc + i], sq_m = a.sq[rc + kmo + i], sq_p = a.sq[rc + kpo + i];
-    const double sdi = (sd_c + sd_e) * 0.5, sdi_p = (sd_cp + sd_ep) * 0.5;
-    const double sdj = (sd_c + sd_s) * 0.5, sdj_p = (sd_cp + sd_sp) * 0.5;
-    const double dus = -((((su_c + su_m) * 0.5) * sdi - ((su_p + su_c) * 0.5) * sdi_p) * inv_ds);
-    const double dvs = -((((sv_c + sv_m) * 0.5) * sdj - ((sv_p + sv_c) * 0.5) * sdj_p) * inv_ds);
-    const double dts = -((((st_c + st_m) * 0.5) * sd_c - ((st_p + st_c) * 0.5) * sd_cp) * inv_ds);
-    const double dqs = -((((sq_c + sq_m) * 0.5) * sd_c - ((sq_p + sq_c) * 0.5) * sd_cp) * inv_ds);
-    // ---- momentum update, dynamics.py:186-212
     const double pb_c = a.p[p_c + i], pb_e = a.p[p_c + ie], pb_s = a.p[p_s + i];
-    const double pu = a.u[rc + kc + i] * ((pb_c + pb_e) * 0.5);
-    const double pv = a.v[rc + kc + i] * ((pb_c + pb_s) * 0.5);
-    const double pgfu = a.pgfu[rc + kc + i];
-    const double pu_n = pu - (dut + dus + pgfu) * dt;
-    const double pv_n = pv - (dvt + dvs + phiv + pgv) * dt;
+    const double iph_pb = (pb_c + pb_e) * 0.5, jph_pb = (pb_c + pb_s) * 0.5;
     const double pn_c = a.pn[p_c + i], pn_e = a.pn[p_c + ie], pn_s = a.pn[p_s + i];
-    double u_n = pu_n * rcp((pn_c + pn_e) * 0.5);
-    double v_n = pv_n * rcp((pn_c + pn_s) * 0.5);
-    if (jg == a.Hg - 1) v_n *= 0.0;                          // v_n[:, -1, :] *= 0, dynamics.py:222
-    // ---- advec_t for t and q, dynamics.py:174-181,214-219
-    const double st_e = a.st[rc + kc + ie], st_w = a.st[rc + kc + iw];
-    const double st_s = a.st[rs + kc + i], st_n = a.st[rn + kc + i];
-    const double sq_e = a.sq[rc + kc + ie], sq_w = a.sq[rc + kc + iw];
-    const double sq_s = a.sq[rs + kc + i], sq_n = a.sq[rn + kc + i];
-    const double adt = (spu_c * ((st_c + st_e) * 0.5) - spu_w * ((st_w + st_c) * 0.5)) * inv_dxj +
-                       (spv_c * ((st_c + st_s) * 0.5) - spv_n * ((st_n + st_c) * 0.5)) * inv_dy;
-    const double adq = (spu_c * ((sq_c + sq_e) * 0.5) - spu_w * ((sq_w + sq_c) * 0.5)) * inv_dxj +
-                       (spv_c * ((sq_c + sq_s) * 0.5) - spv_n * ((sq_n + sq_c) * 0.5)) * inv_dy;
-    const double inv_pn = rcp(pn_c);
-    const double t_n = (a.t[rc + kc + i] * pb_c - (adt + dts) * dt) * inv_pn;
-    const double q_n = (a.q[rc + kc + i] * pb_c - (adq + dqs) * dt) * inv_pn;
-    const long o = (long)j * L * W + kc + i;                 // interior rows: no wrap needed
-    a.ou[o] = u_n;
-    a.ov[o] = v_n;
-    a.ot[o] = t_n;
-    a.oq[o] = q_n;
-    if (k == 0) a.op[(long)j * W + i] = pn_c;
+    const double inv_pnu = rcp((pn_c + pn_e) * 0.5), inv_pnv = rcp((pn_c + pn_s) * 0.5), inv_pn = rcp(pn_c);
+    const bool pole_edge = jg == a.Hg - 1;
+    a.op[(long)j * W + i] = pn_c;
+
+    // vertical window: level k-1 (m), k (c), k+1 (p).  kp()/km() wrap (coordinates_3d.py:55-60):
+    // level -1 is L-1 and level L is 0; both only ever meet sd[0] = 0 (dynamics.py:44).
+    const long top = (long)(L - 1) * W;
+    double su_m = a.su[rc + top + i], sv_m = a.sv[rc + top + i], st_m = a.st[rc + top + i], sq_m = a.sq[rc + top + i];
+    double su_c = a.su[rc + i], sv_c = a.sv[rc + i], st_c = a.st[rc + i], sq_c = a.sq[rc + i];
+    double sd_c = a.sd[rc + i], sd_e = a.sd[rc + ie], sd_s = a.sd[rs + i];
+    const double su_0 = su_c, sv_0 = sv_c, st_0 = st_c, sq_0 = sq_c, sd_c0 = sd_c, sd_e0 = sd_e, sd_s0 = sd_s;
+    for (int k = 0; k < L; ++k) {
+        const long kc = (long)k * W;
+        double su_p, sv_p, st_p, sq_p, sd_cp, sd_ep, sd_sp;
+        if (k + 1 < L) {
+            const long kpo = kc + W;
+            su_p = a.su[rc + kpo + i]; sv_p = a.sv[rc + kpo + i]; st_p = a.st[rc + kpo + i]; sq_p = a.sq[rc + kpo + i];
+            sd_cp = a.sd[rc + kpo + i]; sd_ep = a.sd[rc + kpo + ie]; sd_sp = a.sd[rs + kpo + i];
+        } else {
+            su_p = su_0; sv_p = sv_0; st_p = st_0; sq_p = sq_0;
+            sd_cp = sd_c0; sd_ep = sd_e0; sd_sp = sd_s0;
+        }
+        // stage winds, horizontal neighbours
+        const double su_w = a.su[rc + kc + iw], su_e = a.su[rc + kc + ie];
+        const double su_n = a.su[rn + kc + i], su_s = a.su[rs + kc + i];
+        const double sv_w = a.sv[rc + kc + iw], sv_e = a.sv[rc + kc + ie];
+        const double sv_n = a.sv[rn + kc + i], sv_ne = a.sv[rn + kc + ie], sv_s = a.sv[rs + kc + i];
+        // mass fluxes: spu filtered (K1); spv = sv * jph(sp), dynamics.py:20-22
+        const double spu_c = a.spu[rc + kc + i], spu_w = a.spu[rc + kc + iw], spu_e = a.spu[rc + kc + ie];
+        const double spu_s = a.spu[rs + kc + i], spu_sw = a.spu[rs + kc + iw];
+        const double spv_c = sv_c * jph_c, spv_e = sv_e * jph_ce;
+        const double spv_n = sv_n * jph_n, spv_ne = sv_ne * jph_ne;
+        const double spv_s = sv_s * jph_s;
+        // ---- advec_m_pu, dynamics.py:55-108
+        const double puum = ((su_c + su_w) * 0.5) * ((spu_c + spu_w) * 0.5);
+        const double puup = ((su_e + su_c) * 0.5) * ((spu_e + spu_c) * 0.5);
+        const double puvp = ((spv_c + spv_e) * 0.5) * ((su_c + su_s) * 0.5);
+        const double puvm = ((spv_n + spv_ne) * 0.5) * ((su_n + su_c) * 0.5);
+        const double pvvm = ((sv_c + sv_n) * 0.5) * ((spv_c + spv_n) * 0.5);
+        const double pvvp = ((sv_s + sv_c) * 0.5) * ((spv_s + spv_c) * 0.5);
+        const double pvup = ((sv_c + sv_e) * 0.5) * ((spu_c + spu_s) * 0.5);
+        const double pvum = ((sv_w + sv_c) * 0.5) * ((spu_w + spu_sw) * 0.5);
+        const double dut = (puum - puup) * inv_dxj + (puvm - puvp) * inv_dy + 0.0;
+        const double dvt = (pvvm - pvvp) * inv_dy + (pvum - pvup) * inv_dxh + 0.0;
+        // ---- pgf v-part, dynamics.py:160,167-169 (the u-part went through K3)
+        const double sg = a.sig[k];
+        const double phi_c = a.phi[rc + kc + i], phi_s = a.phi[rs + kc + i];
+        const double rho_c = a.rho[rc + kc + i], rho_s = a.rho[rs + kc + i];
+        const double phiv = jph_c * ((phi_s - phi_c) * inv_dy);
+        const double pgv = ((sg * sp_c + sg * sp_s) * 0.5) * rcp((rho_c + rho_s) * 0.5) * ((sp_s - sp_c) * inv_dy);
+        // ---- vertical advection, dynamics.py:49-52 with iph(sd), jph(sd), sd
+        const double inv_ds = a.inv_dsig[k];
+        const double sdi = (sd_c + sd_e) * 0.5, sdi_p = (sd_cp + sd_ep) * 0.5;
+        const double sdj = (sd_c + sd_s) * 0.5, sdj_p = (sd_cp + sd_sp) * 0.5;
+        const double dus = -((((su_c + su_m) * 0.5) * sdi - ((su_p + su_c) * 0.5) * sdi_p) * inv_ds);
+        const double dvs = -((((sv_c + sv_m) * 0.5) * sdj - ((sv_p + sv_c) * 0.5) * sdj_p) * inv_ds);
+        const double dts = -((((st_c + st_m) * 0.5) * sd_c - ((st_p + st_c) * 0.5) * sd_cp) * inv_ds);
+        const double dqs = -((((sq_c + sq_m) * 0.5) * sd_c - ((sq_p + sq_c) * 0.5) * sd_cp) * inv_ds);
+        // ---- momentum update, dynamics.py:186-212
+        const double pu = a.u[rc + kc + i] * iph_pb;
+        const double pv = a.v[rc + kc + i] * jph_pb;
+        const double pgfu = a.pgfu[rc + kc + i];
+        const double pu_n = pu - (dut + dus + pgfu) * dt;
+        const double pv_n = pv - (dvt + dvs + phiv + pgv) * dt;
+        double u_n = pu_n * inv_pnu;
+        double v_n = pv_n * inv_pnv;
+        if (pole_edge) v_n *= 0.0;                               // v_n[:, -1, :] *= 0, dynamics.py:222
+        // ---- advec_t for t and q, dynamics.py:174-181,214-219
+        const double st_e = a.st[rc + kc + ie], st_w = a.st[rc + kc + iw];
+        const double st_s = a.st[rs + kc + i], st_n = a.st[rn + kc + i];
+        const double sq_e = a.sq[rc + kc + ie], sq_w = a.sq[rc + kc + iw];
+        const double sq_s = a.sq[rs + kc + i], sq_n = a.sq[rn + kc + i];
+        const double adt = (spu_c * ((st_c + st_e) * 0.5) - spu_w * ((st_w + st_c) * 0.5)) * inv_dxj +
+                           (spv_c * ((st_c + st_s) * 0.5) - spv_n * ((st_n + st_c) * 0.5)) * inv_dy;
+        const double adq = (spu_c * ((sq_c + sq_e) * 0.5) - spu_w * ((sq_w + sq_c) * 0.5)) * inv_dxj +
+                           (spv_c * ((sq_c + sq_s) * 0.5) - spv_n * ((sq_n + sq_c) * 0.5)) * inv_dy;
+        const double t_n = (a.t[rc + kc + i] * pb_c - (adt + dts) * dt) * inv_pn;
+        const double q_n = (a.q[rc + kc + i] * pb_c - (adq + dqs) * dt) * inv_pn;
+        const long o = (long)j * L * W + kc + i;                 // interior rows: no wrap needed
+        a.ou[o] = u_n;
+        a.ov[o] = v_n;
+        a.ot[o] = t_n;
+        a.oq[o] = q_n;
+        // rotate the vertical window
+        su_m = su_c; sv_m = sv_c; st_m = st_c; sq_m = sq_c;
+        su_c = su_p; sv_c = sv_p; st_c = st_p; sq_c = sq_p;
+        sd_c = sd_cp; sd_e = sd_ep; sd_s = sd_sp;
+    }
 }
 
 // ---------------------------------------------------------------- calc_energy (no_limits_2_5d.py:35-60)
@@ -754,7 +781,10 @@ static void half(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1
     a.j1 = j1;
     hipLaunchKernelGGL(pe_pgf_filter_kernel, dim3(a.j1 - a.j0, pairs), dim3(256), lds, s, a);
     tick(m, s);
-    hipLaunchKernelGGL(pe_update_kernel, dim3((W + 255) / 256, L, a.j1 - a.j0), dim3(256), 0, s, a);
+    {
+        const long tiles = (long)((W + 255) / 256) * (a.j1 - a.j0);
+        hipLaunchKernelGGL(pe_update_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, s, a);
+    }
     tick(m, s);
 }
 
