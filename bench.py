@@ -252,7 +252,7 @@ def main():
                 continue
             if cx.world > 1 and name == "c2":
                 continue                                   # 360 rows: not a multi-GPU workload
-            st, wu = {"c2": (1000, 50), "c3": (100, 10), "c4": (16, 3)}[name]
+            st, wu = {"c2": (600, 50), "c3": (100, 10), "c4": (16, 3)}[name]      # c2: the noise IC goes unstable (in the reference too) near step 1300
             r = run_workload(cx, name, st, wu, want_kernel=cx.world == 1)
             if cx.world > 1:                               # same-run single-GPU reference (rank 0 alone)
                 r1 = run_workload(cx, name, max(st // 2, 4), 2, world=1, want_kernel=False)

@@ -219,15 +219,26 @@ __global__ __launch_bounds__(256) void pe_spu_filter_kernel(PeArgs a) {
 }
 
 // ---------------------------------------------------------------- K2: column kernel
-__global__ __launch_bounds__(256) void pe_column_kernel(PeArgs a) {
+// The per-level values that the two scans need twice (conv for the reverse cumulative sum,
+// stp for phi) are parked in LDS, park[k][thread], instead of a round trip through HBM.
+constexpr int kColThreads = 128;
+__global__ __launch_bounds__(kColThreads) void pe_column_kernel(PeArgs a) {
     __shared__ double tab[kExnerTabDoubles];
-    tab[threadIdx.x] = a.exner_tab[threadIdx.x];
+    extern __shared__ double park[];                 // [L][kColThreads]
+    for (int n = threadIdx.x; n < kExnerTabDoubles; n += kColThreads) tab[n] = a.exner_tab[n];
     __syncthreads();
     const Idx ix{a.W, a.H, a.L, a.wrap};
     const int W = a.W, L = a.L;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int j = a.j0 + blockIdx.y;
+    // tiles (row, column block) in contiguous runs of rows per XCD, as pe_update_kernel
+    const int iblocks = (W + kColThreads - 1) / kColThreads;
+    const int per_xcd = gridDim.x / 8;
+    const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const int jrel = tile / iblocks;
+    if (jrel >= a.j1 - a.j0) return;
+    const int i = (tile - jrel * iblocks) * kColThreads + threadIdx.x;
+    const int j = a.j0 + jrel;
     if (i >= W) return;
+    double *pk = park + threadIdx.x;
     const int iw = i == 0 ? W - 1 : i - 1;
     const int jg = wrapi(a.row0 + j, a.Hg);
     const double inv_dxj = a.inv_dxj[jg], inv_dy = a.inv_dy;
@@ -242,24 +253,21 @@ __global__ __launch_bounds__(256) void pe_column_kernel(PeArgs a) {
         const double spv_n = a.sv[n3 + (long)k * W + i] * jph_n;
         const double conv = ((a.spu[o + i] - a.spu[o + iw]) * inv_dxj + (spv_c - spv_n) * inv_dy) * a.dsig[k];
         pit += conv;             // np.sum over k, ascending
-        a.sd[o + i] = conv;      // parked; turned into sigma-dot below
+        pk[k * kColThreads] = conv;
     }
     a.pit[ix.r2(j) + i] = pit;
     a.pn[ix.r2(j) + i] = a.p[ix.r2(j) + i] - pit * a.dt;   // p_n = p - pit dt, dynamics.py:194
     double rc = 0.0;
     for (int k = L - 1; k >= 1; --k) {                       // cumsum(conv[::-1])[::-1]
-        const long o = c3 + (long)k * W + i;
-        rc += a.sd[o];
-        a.sd[o] = rc - pit * a.sigb[k];
+        rc += pk[k * kColThreads];
+        a.sd[c3 + (long)k * W + i] = rc - pit * a.sigb[k];
     }
     a.sd[c3 + i] = 0.0;                                      // sd[0] = 0, dynamics.py:44
     // ---- compute_geopotential, dynamics.py:111-143
     const double hmG = a.heightmap ? a.heightmap[(long)jg * W + i] * kG : 0.0 * kG;
-    double t0 = 0.0, ex0 = 0.0;                              // level 0, for the k wrap at the top
     double t_k = a.st[c3 + i];
     double ex_k = exner(spc * a.sig[0] + a.ptop, tab);
-    t0 = t_k;
-    ex0 = ex_k;
+    const double t0 = t_k, ex0 = ex_k;                       // level 0, for the k wrap at the top
     double acc = 0.0;
     for (int k = 0; k < L; ++k) {
         const long o = c3 + (long)k * W + i;
@@ -279,19 +287,15 @@ __global__ __launch_bounds__(256) void pe_column_kernel(PeArgs a) {
         const double stp = kCp * ((t_k + t_n) * 0.5) * (ex_k - ex_n);
         const double s2 = a.sigt[k] * stp;
         acc += s1 - s2;
-        a.phi[o] = stp;          // parked
+        pk[k * kColThreads] = stp;
         t_k = t_n;
         ex_k = ex_n;
     }
     double run = acc + hmG;                                  // stp_n[0], dynamics.py:132
-    double prev = a.phi[c3 + i];
     a.phi[c3 + i] = run;
-    for (int k = 1; k < L; ++k) {                            // phi = cumsum(stp_n)
-        const long o = c3 + (long)k * W + i;
-        const double cur = a.phi[o];
-        run += prev;
-        a.phi[o] = run;
-        prev = cur;
+    for (int k = 1; k < L; ++k) {                            // phi = cumsum(stp_n), stp_n = km(stp)
+        run += pk[(k - 1) * kColThreads];
+        a.phi[c3 + (long)k * W + i] = run;
     }
 }
 
@@ -658,6 +662,14 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
     if (hipFuncSetAttribute((const void *)pe_spu_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess ||
         hipFuncSetAttribute((const void *)pe_pgf_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
         return bad("dynamic LDS size");
+    if ((size_t)L * kColThreads * sizeof(double) + kExnerTabDoubles * sizeof(double) > 160 * 1024) {
+        *err = "GCM_PE25D: too many layers for the column kernel's LDS (max 158)";
+        pe25d_destroy(m);
+        return nullptr;
+    }
+    if (hipFuncSetAttribute((const void *)pe_column_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(L * kColThreads * sizeof(double))) != hipSuccess)
+        return bad("dynamic LDS size (column kernel)");
     if (W > 1) {
         // filter multiplier, low_pass.py:61-72, same expression order as the reference
         const int nh = W / 2 + 1;
@@ -777,7 +789,11 @@ static void half(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1
     a.j0 = j0;
     a.j1 = j1 + ext;
     hipLaunchKernelGGL(pe_spu_filter_kernel, dim3(a.j1 - a.j0, pairs), dim3(256), lds, s, a);
-    hipLaunchKernelGGL(pe_column_kernel, dim3((W + 255) / 256, a.j1 - a.j0), dim3(256), 0, s, a);
+    {
+        const long tiles = (long)((W + kColThreads - 1) / kColThreads) * (a.j1 - a.j0);
+        hipLaunchKernelGGL(pe_column_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kColThreads),
+                           sizeof(double) * (size_t)L * kColThreads, s, a);
+    }
     a.j1 = j1;
     hipLaunchKernelGGL(pe_pgf_filter_kernel, dim3(a.j1 - a.j0, pairs), dim3(256), lds, s, a);
     tick(m, s);
