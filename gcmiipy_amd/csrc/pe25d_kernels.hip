@@ -7,7 +7,7 @@
 //
 // One half_timestep (dynamics.py:183-227) is four launches:
 //   K1 spu_filter   spu = arakawa_1977(su * iph(sp))            one workgroup per (row, level pair)
-//   K2 column       conv, pit, sigma-dot, p_n; rho, phi          one thread per (j, i) column
+//   K2 column       conv, pit, p_n; rho, phi (sigma-dot is rebuilt in K4)  one thread per (j, i) column
 //   K3 pgf_filter   pgfu = arakawa_1977(pgu + phiu)              one workgroup per (row, level pair)
 //   K4 update       advec_m_pu, advec_sig, advec_t, un_pu/un_pv  one thread per cell
 // The zonal filter is a complex Stockham FFT in LDS: two levels of one row are packed as
@@ -37,7 +37,7 @@ struct PeArgs {
     const double *sp, *su, *sv, *st, *sq;
     double *op, *ou, *ov, *ot, *oq;
     // intermediates
-    double *spu, *sd, *phi, *rho, *pgfu;   // 3-D
+    double *spu, *phi, *rho, *pgfu;        // 3-D
     double *pit, *pn;                      // 2-D
     // tables (device)
     const double *inv_dxj, *inv_dxh;       // [Hg] reciprocals of geometry.py:136-137
@@ -245,24 +245,17 @@ __global__ __launch_bounds__(kColThreads) void pe_column_kernel(PeArgs a) {
     const double spc = a.sp[ix.r2(j) + i], spn = a.sp[ix.r2(j - 1) + i], sps = a.sp[ix.r2(j + 1) + i];
     const double jph_c = (spc + sps) * 0.5, jph_n = (spn + spc) * 0.5;  // jph(sp) at j, j-1
     const long c3 = ix.r3(j), n3 = ix.r3(j - 1);
-    // ---- aflux, dynamics.py:35-46
+    // ---- aflux, dynamics.py:35-46: pit = sum_k conv (ascending, as np.sum over the outer axis).
+    // sigma-dot itself is not materialised: the update kernel rebuilds it on the fly from pit.
     double pit = 0.0;
     for (int k = 0; k < L; ++k) {
         const long o = c3 + (long)k * W;
         const double spv_c = a.sv[o + i] * jph_c;
         const double spv_n = a.sv[n3 + (long)k * W + i] * jph_n;
-        const double conv = ((a.spu[o + i] - a.spu[o + iw]) * inv_dxj + (spv_c - spv_n) * inv_dy) * a.dsig[k];
-        pit += conv;             // np.sum over k, ascending
-        pk[k * kColThreads] = conv;
+        pit += ((a.spu[o + i] - a.spu[o + iw]) * inv_dxj + (spv_c - spv_n) * inv_dy) * a.dsig[k];
     }
     a.pit[ix.r2(j) + i] = pit;
     a.pn[ix.r2(j) + i] = a.p[ix.r2(j) + i] - pit * a.dt;   // p_n = p - pit dt, dynamics.py:194
-    double rc = 0.0;
-    for (int k = L - 1; k >= 1; --k) {                       // cumsum(conv[::-1])[::-1]
-        rc += pk[k * kColThreads];
-        a.sd[c3 + (long)k * W + i] = rc - pit * a.sigb[k];
-    }
-    a.sd[c3 + i] = 0.0;                                      // sd[0] = 0, dynamics.py:44
     // ---- compute_geopotential, dynamics.py:111-143
     const double hmG = a.heightmap ? a.heightmap[(long)jg * W + i] * kG : 0.0 * kG;
     double t_k = a.st[c3 + i];
@@ -377,23 +370,27 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgs a) {
     const bool pole_edge = jg == a.Hg - 1;
     a.op[(long)j * W + i] = pn_c;
 
-    // vertical window: level k-1 (m), k (c), k+1 (p).  kp()/km() wrap (coordinates_3d.py:55-60):
-    // level -1 is L-1 and level L is 0; both only ever meet sd[0] = 0 (dynamics.py:44).
+    // The levels are marched from the top down, because sigma-dot is the top-down running sum of
+    // conv (dynamics.py:42: cumsum(conv[::-1])[::-1] - pit sigb, sd[0] = 0): it is rebuilt here,
+    // for this column and its east and south neighbours (iph(sd), jph(sd)), from the mass fluxes
+    // the momentum advection loads anyway, instead of being read back from HBM.
+    // Vertical window: level k+1 (p), k (c), k-1 (m).  kp()/km() wrap (coordinates_3d.py:55-60):
+    // level L is 0 and level -1 is L-1; both only ever meet sd[0] = 0.
+    const double inv_dxj_s = a.inv_dxj[wrapi(a.row0 + j + 1, a.Hg)];
+    const double pit_c = a.pit[p_c + i], pit_e = a.pit[p_c + ie], pit_s = a.pit[p_s + i];
     const long top = (long)(L - 1) * W;
-    double su_m = a.su[rc + top + i], sv_m = a.sv[rc + top + i], st_m = a.st[rc + top + i], sq_m = a.sq[rc + top + i];
-    double su_c = a.su[rc + i], sv_c = a.sv[rc + i], st_c = a.st[rc + i], sq_c = a.sq[rc + i];
-    double sd_c = a.sd[rc + i], sd_e = a.sd[rc + ie], sd_s = a.sd[rs + i];
-    const double su_0 = su_c, sv_0 = sv_c, st_0 = st_c, sq_0 = sq_c, sd_c0 = sd_c, sd_e0 = sd_e, sd_s0 = sd_s;
-    for (int k = 0; k < L; ++k) {
+    double su_p = a.su[rc + i], sv_p = a.sv[rc + i], st_p = a.st[rc + i], sq_p = a.sq[rc + i];   // level L -> 0
+    double su_c = a.su[rc + top + i], sv_c = a.sv[rc + top + i], st_c = a.st[rc + top + i], sq_c = a.sq[rc + top + i];
+    double sd_cp = 0.0, sd_ep = 0.0, sd_sp = 0.0;            // sd at level k+1; level L wraps to sd[0] = 0
+    double rc_c = 0.0, rc_e = 0.0, rc_s = 0.0;               // running sums of conv from the top
+    for (int k = L - 1; k >= 0; --k) {
         const long kc = (long)k * W;
-        double su_p, sv_p, st_p, sq_p, sd_cp, sd_ep, sd_sp;
-        if (k + 1 < L) {
-            const long kpo = kc + W;
-            su_p = a.su[rc + kpo + i]; sv_p = a.sv[rc + kpo + i]; st_p = a.st[rc + kpo + i]; sq_p = a.sq[rc + kpo + i];
-            sd_cp = a.sd[rc + kpo + i]; sd_ep = a.sd[rc + kpo + ie]; sd_sp = a.sd[rs + kpo + i];
+        double su_m, sv_m, st_m, sq_m;
+        if (k > 0) {
+            const long kmo = kc - W;
+            su_m = a.su[rc + kmo + i]; sv_m = a.sv[rc + kmo + i]; st_m = a.st[rc + kmo + i]; sq_m = a.sq[rc + kmo + i];
         } else {
-            su_p = su_0; sv_p = sv_0; st_p = st_0; sq_p = sq_0;
-            sd_cp = sd_c0; sd_ep = sd_e0; sd_sp = sd_s0;
+            su_m = a.su[rc + top + i]; sv_m = a.sv[rc + top + i]; st_m = a.st[rc + top + i]; sq_m = a.sq[rc + top + i];
         }
         // stage winds, horizontal neighbours
         const double su_w = a.su[rc + kc + iw], su_e = a.su[rc + kc + ie];
@@ -406,6 +403,17 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgs a) {
         const double spv_c = sv_c * jph_c, spv_e = sv_e * jph_ce;
         const double spv_n = sv_n * jph_n, spv_ne = sv_ne * jph_ne;
         const double spv_s = sv_s * jph_s;
+        // ---- aflux, dynamics.py:35-46, at (j,i), (j,i+1), (j+1,i)
+        const double dsg = a.dsig[k], sgb = a.sigb[k];
+        double sd_c = 0.0, sd_e = 0.0, sd_s = 0.0;           // sd[0] = 0, dynamics.py:44
+        if (k > 0) {
+            rc_c += ((spu_c - spu_w) * inv_dxj + (spv_c - spv_n) * inv_dy) * dsg;
+            rc_e += ((spu_e - spu_c) * inv_dxj + (spv_e - spv_ne) * inv_dy) * dsg;
+            rc_s += ((spu_s - spu_sw) * inv_dxj_s + (spv_s - spv_c) * inv_dy) * dsg;
+            sd_c = rc_c - pit_c * sgb;
+            sd_e = rc_e - pit_e * sgb;
+            sd_s = rc_s - pit_s * sgb;
+        }
         // ---- advec_m_pu, dynamics.py:55-108
         const double puum = ((su_c + su_w) * 0.5) * ((spu_c + spu_w) * 0.5);
         const double puup = ((su_e + su_c) * 0.5) * ((spu_e + spu_c) * 0.5);
@@ -456,10 +464,10 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgs a) {
         a.ov[o] = v_n;
         a.ot[o] = t_n;
         a.oq[o] = q_n;
-        // rotate the vertical window
-        su_m = su_c; sv_m = sv_c; st_m = st_c; sq_m = sq_c;
-        su_c = su_p; sv_c = sv_p; st_c = st_p; sq_c = sq_p;
-        sd_c = sd_cp; sd_e = sd_ep; sd_s = sd_sp;
+        // rotate the vertical window downwards
+        su_p = su_c; sv_p = sv_c; st_p = st_c; sq_p = sq_c;
+        su_c = su_m; sv_c = sv_m; st_c = st_m; sq_c = sq_m;
+        sd_cp = sd_c; sd_ep = sd_e; sd_sp = sd_s;
     }
 }
 
@@ -543,7 +551,7 @@ struct Pe25d {
     double *st[3][GCM_NFIELDS] = {};
     int cur_i = 0;
     bool star_valid = false;
-    double *spu = nullptr, *sd = nullptr, *phi = nullptr, *rho = nullptr, *pgfu = nullptr;
+    double *spu = nullptr, *phi = nullptr, *rho = nullptr, *pgfu = nullptr;
     double *pit = nullptr, *pn = nullptr, *stage3 = nullptr;  // stage3: transpose staging
     double *inv_dxj = nullptr, *inv_dxh = nullptr, *sig = nullptr, *dsig = nullptr,
            *inv_dsig = nullptr, *sigb = nullptr, *sigt = nullptr, *heightmap = nullptr,
@@ -628,7 +636,7 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
             if (!dev_upload<double>(m, &d, nullptr, n)) return bad("state");
             m->st[s][f] = d + (size_t)kGhost * W * (f == GCM_P ? 1 : L);
         }
-    double **inter3[] = {&m->spu, &m->sd, &m->phi, &m->rho, &m->pgfu};
+    double **inter3[] = {&m->spu, &m->phi, &m->rho, &m->pgfu};
     for (double **pp : inter3) {
         double *d = nullptr;
         if (!dev_upload<double>(m, &d, nullptr, n3)) return bad("intermediate");
@@ -759,7 +767,7 @@ static PeArgs make_args(Pe25d *m, int stage_set, int out_set, double dt) {
     a.p = B[GCM_P]; a.u = B[GCM_U]; a.v = B[GCM_V]; a.t = B[GCM_T]; a.q = B[GCM_Q];
     a.sp = S[GCM_P]; a.su = S[GCM_U]; a.sv = S[GCM_V]; a.st = S[GCM_T]; a.sq = S[GCM_Q];
     a.op = O[GCM_P]; a.ou = O[GCM_U]; a.ov = O[GCM_V]; a.ot = O[GCM_T]; a.oq = O[GCM_Q];
-    a.spu = m->spu; a.sd = m->sd; a.phi = m->phi; a.rho = m->rho; a.pgfu = m->pgfu;
+    a.spu = m->spu; a.phi = m->phi; a.rho = m->rho; a.pgfu = m->pgfu;
     a.pit = m->pit; a.pn = m->pn;
     a.inv_dxj = m->inv_dxj; a.inv_dxh = m->inv_dxh;
     a.sig = m->sig; a.dsig = m->dsig; a.inv_dsig = m->inv_dsig; a.sigb = m->sigb; a.sigt = m->sigt;
