@@ -32,7 +32,7 @@ class Config(C.Structure):
         ("device", C.c_int32), ("halo_steps", C.c_int32),
         ("dx", C.c_double), ("dy", C.c_double), ("ptop", C.c_double),
         ("dx_j", _dp), ("dx_h", _dp), ("sig", _dp), ("dsig", _dp), ("sigb", _dp),
-        ("sigt", _dp), ("heightmap", _dp), ("stream", C.c_void_p),
+        ("sigt", _dp), ("heightmap", _dp), ("cor_u", _dp), ("cor_v", _dp), ("stream", C.c_void_p),
     ]
 
 

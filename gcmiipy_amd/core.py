@@ -48,7 +48,7 @@ class Core:
 
     def __init__(self, model, width, height, layers=1, dx=0.0, tracer=_lib.TRACER_NONE,
                  variant=_lib.VARIANT_AUTO, geom=None, filter=True, nranks=1, rank=0,
-                 global_height=None, row0=0, device=-1, stream=None, halo_steps=1):
+                 global_height=None, row0=0, device=-1, stream=None, halo_steps=1, coriolis=False):
         self.model, self.W, self.H, self.L = model, int(width), int(height), int(layers)
         self.nranks, self.rank = nranks, rank
         cfg = _lib.Config()
@@ -81,6 +81,10 @@ class Core:
             cfg.sig, cfg.dsig = tab(geom.sig, self.L), tab(geom.dsig, self.L)
             cfg.sigb, cfg.sigt = tab(geom.sigb, self.L), tab(geom.sigt, self.L)
             cfg.heightmap = tab(geom.heightmap, gh * self.W)
+            if coriolis:
+                from .geometry import coriolis_tables
+                cu, cv = coriolis_tables(geom)
+                cfg.cor_u, cfg.cor_v = tab(cu, gh), tab(cv, gh)
         self._h = _lib._H()
         rc = lib.gcm_create(C.byref(cfg), C.byref(self._h))
         if rc != _lib.OK:

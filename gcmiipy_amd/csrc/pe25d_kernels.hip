@@ -43,6 +43,7 @@ struct PeArgs {
     const double *inv_dxj, *inv_dxh;       // [Hg] reciprocals of geometry.py:136-137
     const double *sig, *dsig, *inv_dsig, *sigb, *sigt;  // [L]
     const double *heightmap;               // [Hg][W] (global rows) or null
+    const double *cor_u, *cor_v;           // [Hg] Coriolis factors or null (dynamics.py:82-92)
     const double *smul;                    // [Hg][W/2+1] filter multiplier (low_pass.py:61-72)
     const double2 *tw;                     // [W] exp(-2 pi i n / W)
     const double *exner_tab;
@@ -368,6 +369,8 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgs a) {
     const double pn_c = a.pn[p_c + i], pn_e = a.pn[p_c + ie], pn_s = a.pn[p_s + i];
     const double inv_pnu = rcp((pn_c + pn_e) * 0.5), inv_pnv = rcp((pn_c + pn_s) * 0.5), inv_pn = rcp(pn_c);
     const bool pole_edge = jg == a.Hg - 1;
+    const bool coriolis = a.cor_u != nullptr;
+    const double cp_u = coriolis ? a.cor_u[jg] : 0.0, cp_v = coriolis ? a.cor_v[jg] : 0.0;
     a.op[(long)j * W + i] = pn_c;
 
     // The levels are marched from the top down, because sigma-dot is the top-down running sum of
@@ -423,8 +426,15 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgs a) {
         const double pvvp = ((sv_s + sv_c) * 0.5) * ((spv_s + spv_c) * 0.5);
         const double pvup = ((sv_c + sv_e) * 0.5) * ((spu_c + spu_s) * 0.5);
         const double pvum = ((sv_w + sv_c) * 0.5) * ((spu_w + spu_sw) * 0.5);
-        const double dut = (puum - puup) * inv_dxj + (puvm - puvp) * inv_dy + 0.0;
-        const double dvt = (pvvm - pvvp) * inv_dy + (pvum - pvup) * inv_dxh + 0.0;
+        double cor_u = 0.0, cor_v = 0.0;                         // the reference adds a literal 0
+        if (coriolis) {                                          // dynamics.py:83-92
+            const double pu_at_pv = (((spu_c + spu_s) * 0.5) + ((spu_w + spu_sw) * 0.5)) * 0.5;    // imh(jph(pu))
+            const double pv_at_pu = (((spv_c + spv_n) * 0.5) + ((spv_e + spv_ne) * 0.5)) * 0.5;    // iph(jmh(pv))
+            cor_u = cp_u * -pv_at_pu;
+            cor_v = cp_v * pu_at_pv;
+        }
+        const double dut = (puum - puup) * inv_dxj + (puvm - puvp) * inv_dy + cor_u;
+        const double dvt = (pvvm - pvvp) * inv_dy + (pvum - pvup) * inv_dxh + cor_v;
         // ---- pgf v-part, dynamics.py:160,167-169 (the u-part went through K3)
         const double sg = a.sig[k];
         const double phi_c = a.phi[rc + kc + i], phi_s = a.phi[rs + kc + i];
@@ -553,6 +563,7 @@ struct Pe25d {
     bool star_valid = false;
     double *spu = nullptr, *phi = nullptr, *rho = nullptr, *pgfu = nullptr;
     double *pit = nullptr, *pn = nullptr, *stage3 = nullptr;  // stage3: transpose staging
+    double *cor_u = nullptr, *cor_v = nullptr;
     double *inv_dxj = nullptr, *inv_dxh = nullptr, *sig = nullptr, *dsig = nullptr,
            *inv_dsig = nullptr, *sigb = nullptr, *sigt = nullptr, *heightmap = nullptr,
            *smul = nullptr, *exner_tab = nullptr;
@@ -663,6 +674,13 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
         return bad("tables");
     if (cfg.heightmap && !dev_upload(m, &m->heightmap, cfg.heightmap, (size_t)Hg * W))
         return bad("heightmap");
+    if ((cfg.cor_u != nullptr) != (cfg.cor_v != nullptr)) {
+        *err = "GCM_PE25D: cor_u and cor_v must be given together";
+        pe25d_destroy(m);
+        return nullptr;
+    }
+    if (cfg.cor_u && (!dev_upload(m, &m->cor_u, cfg.cor_u, Hg) || !dev_upload(m, &m->cor_v, cfg.cor_v, Hg)))
+        return bad("coriolis tables");
     double tab[kExnerTabDoubles];
     build_exner_table(tab);
     if (!dev_upload(m, &m->exner_tab, tab, kExnerTabDoubles)) return bad("exner table");
@@ -771,7 +789,7 @@ static PeArgs make_args(Pe25d *m, int stage_set, int out_set, double dt) {
     a.pit = m->pit; a.pn = m->pn;
     a.inv_dxj = m->inv_dxj; a.inv_dxh = m->inv_dxh;
     a.sig = m->sig; a.dsig = m->dsig; a.inv_dsig = m->inv_dsig; a.sigb = m->sigb; a.sigt = m->sigt;
-    a.heightmap = m->heightmap; a.smul = m->smul; a.tw = m->tw; a.exner_tab = m->exner_tab;
+    a.heightmap = m->heightmap; a.cor_u = m->cor_u; a.cor_v = m->cor_v; a.smul = m->smul; a.tw = m->tw; a.exner_tab = m->exner_tab;
     a.plan = m->plan;
     a.W = m->W; a.H = m->H; a.L = m->L; a.Hg = m->Hg; a.row0 = m->cfg.row0;
     a.wrap = m->wrap ? 1 : 0;

@@ -15,14 +15,14 @@ def _geom_key(geom):
             np.asarray(geom.heightmap).tobytes())
 
 
-def core_for(geom, filter=True):
-    key = (_geom_key(geom), filter)
+def core_for(geom, filter=True, coriolis=False):
+    key = (_geom_key(geom), filter, coriolis)
     c = _cache.get(key)
     if c is None:
         if len(_cache) > 4:
             _cache.popitem()[1].close()
         c = _cache[key] = Core(_lib.PE25D, geom.width, geom.height, geom.layers, geom=geom,
-                               filter=filter)
+                               filter=filter, coriolis=coriolis)
     return c
 
 
@@ -49,12 +49,13 @@ def half_timestep(p, u, v, t, q, sp, su, sv, st, sq, dt, geom):
     return _wrap_out(c.get_state(), units)
 
 
-def matsuno_timestep(p, u, v, t, q, dt, geom, boundary_conditions=None):
-    """dynamics.py:230-237.  With a Python `boundary_conditions(sp,su,sv,st,sq,dt,geom)` hook
+def matsuno_timestep(p, u, v, t, q, dt, geom, boundary_conditions=None, coriolis=False):
+    """dynamics.py:230-237.  `coriolis=True` switches on the Coriolis terms the reference keeps
+    behind `if False` (dynamics.py:82-92).  With a Python `boundary_conditions(sp,su,sv,st,sq,dt,geom)` hook
     the predicted state makes a host round trip between the stages (documented slow path);
     with None both stages stay on the device."""
     base, units = _prep(p, u, v, t, q, geom)
-    c = core_for(geom)
+    c = core_for(geom, coriolis=coriolis)
     c.set_state(*base)
     dts = scalar(dt)
     if boundary_conditions is None:

@@ -81,3 +81,12 @@ def gen_square_geometry(height, width, layers, dx, dy, sig_func=equal_sig):
     geom.dy = float(dy)
     geom.heightmap = np.zeros((height, width))
     return geom
+
+
+def coriolis_tables(geom):
+    """cp_at_u, cp_at_v of the (disabled) Coriolis branch, dynamics.py:85-89: per latitude row,
+    2 sin(lat) w and 2 sin(jph(lat)) w with w = 2 pi / day; geom.lat in radians."""
+    w = 2 * math.pi / 86400.0
+    lat = np.asarray(geom.lat, dtype=np.float64).reshape(-1)
+    lat_h = (lat + np.roll(lat, -1)) / 2                       # jph(geom.lat), wraps like np.roll
+    return 2 * np.sin(lat) * w, 2 * np.sin(lat_h) * w

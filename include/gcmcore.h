@@ -100,6 +100,11 @@ typedef struct {
     const double *sigb;    /* [L] */
     const double *sigt;    /* [L] */
     const double *heightmap; /* [global_height][W] (all rows), or NULL for flat topography       */
+    /* Coriolis terms of advec_m_pu (dynamics.py:82-92; switched off by `if False` in the
+     * reference): cor_u[j] = 2 sin(lat_j) w, cor_v[j] = 2 sin(jph(lat)_j) w, w = 2 pi / day.
+     * Both NULL = the reference's literal 0.                                                   */
+    const double *cor_u;   /* [global_height] */
+    const double *cor_v;   /* [global_height] */
     void *stream;          /* hipStream_t to launch on; NULL = the null stream                   */
 } gcm_config;
 

@@ -33,9 +33,10 @@ def advec_sig(sd, q, geom):
     return -dq
 
 
-def advec_m_pu(p, u, v, pu, pv, geom):
-    """dynamics.py:55-108 (Coriolis branch disabled by `if False`, :82;
-    the literal 0 is still added, :94-95,103-104)."""
+def advec_m_pu(p, u, v, pu, pv, geom, coriolis=False):
+    """dynamics.py:55-108.  The Coriolis branch is disabled by `if False` (:82) and the
+    literal 0 is added instead (:94-95,103-104); `coriolis=True` restates the disabled
+    branch (:83-92) as written."""
     puum = imh(u) * imh(pu)
     puup = ipj(puum)
     puvp = iph(pv) * jph(u)
@@ -44,8 +45,18 @@ def advec_m_pu(p, u, v, pu, pv, geom):
     pvvp = ijp(pvvm)
     pvup = iph(v) * jph(pu)
     pvum = imj(pvup)
-    coriolis_u = 0.0
-    coriolis_v = coriolis_u
+    if coriolis:
+        import math
+        pu_at_pv = imh(jph(pu))
+        pv_at_pu = iph(jmh(pv))
+        w = 2 * math.pi / 86400.0
+        cp_at_u = 2 * np.sin(geom.lat) * w
+        cp_at_v = 2 * np.sin(jph(geom.lat)) * w
+        coriolis_u = cp_at_u * -pv_at_pu
+        coriolis_v = cp_at_v * pu_at_pv
+    else:
+        coriolis_u = 0.0
+        coriolis_v = coriolis_u
     dut = (puum - puup) / geom.dx_j + (puvm - puvp) / geom.dy + coriolis_u
     dvt = (pvvm - pvvp) / geom.dy + (pvum - pvup) / geom.dx_h + coriolis_v
     return dut, dvt
@@ -93,7 +104,7 @@ def advec_t(pu, pv, t, geom):
     return (tpu - imj(tpu)) / geom.dx_j + (tpv - ijm(tpv)) / geom.dy
 
 
-def half_timestep(p, u, v, t, q, sp, su, sv, st, sq, dt, geom, _tap=None):
+def half_timestep(p, u, v, t, q, sp, su, sv, st, sq, dt, geom, _tap=None, coriolis=False):
     """dynamics.py:183-227.  `_tap`, if a dict, receives every intermediate
     (test instrumentation only)."""
     pu = calc_pu(p, u)
@@ -105,7 +116,7 @@ def half_timestep(p, u, v, t, q, sp, su, sv, st, sq, dt, geom, _tap=None):
     pit, sd = aflux(spu, spv, geom)
     p_n = p - pit * dt
 
-    dut, dvt = advec_m_pu(sp, su, sv, spu, spv, geom)
+    dut, dvt = advec_m_pu(sp, su, sv, spu, spv, geom, coriolis)
     pgu, pgv, phiu, phiv = pgf(sp, st, geom)
     dus = advec_sig(iph(sd), su, geom)
     dvs = advec_sig(jph(sd), sv, geom)
@@ -130,12 +141,12 @@ def half_timestep(p, u, v, t, q, sp, su, sv, st, sq, dt, geom, _tap=None):
     return p_n, u_n, v_n, t_n, q_n
 
 
-def matsuno_timestep(p, u, v, t, q, dt, geom, boundary_conditions=None):
+def matsuno_timestep(p, u, v, t, q, dt, geom, boundary_conditions=None, coriolis=False):
     """dynamics.py:230-237."""
-    sp, su, sv, st, sq = half_timestep(p, u, v, t, q, p, u, v, t, q, dt, geom)
+    sp, su, sv, st, sq = half_timestep(p, u, v, t, q, p, u, v, t, q, dt, geom, coriolis=coriolis)
     if boundary_conditions:
         sp, su, sv, st, sq = boundary_conditions(sp, su, sv, st, sq, dt, geom)
-    op, ou, ov, ot, oq = half_timestep(p, u, v, t, q, sp, su, sv, st, sq, dt, geom)
+    op, ou, ov, ot, oq = half_timestep(p, u, v, t, q, sp, su, sv, st, sq, dt, geom, coriolis=coriolis)
     if boundary_conditions:
         op, ou, ov, ot, oq = boundary_conditions(op, ou, ov, ot, oq, dt, geom)
     return op, ou, ov, ot, oq

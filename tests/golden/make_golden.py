@@ -448,7 +448,36 @@ def g11_temperature():
              C.standard_pressure)))]))
 
 
+def g12_coriolis():
+    """The reference keeps its Coriolis terms behind a literal `if False:` (dynamics.py:82).
+    To pin the build's optional Coriolis path against the author's own expressions, the module
+    source is read as text, that one literal is flipped to `if True:` IN MEMORY and the result is
+    executed as a module (nothing is written to disk); everything else is the unmodified file."""
+    import types
+    src = open(os.path.join(REF, "dynamics.py")).read()
+    assert src.count("    if False:\n        pu_at_pv = imh(jph(pu))") == 1
+    src = src.replace("    if False:\n        pu_at_pv = imh(jph(pu))", "    if True:\n        pu_at_pv = imh(jph(pu))")
+    mod = types.ModuleType("dynamics_coriolis_on")
+    mod.__file__ = os.path.join(REF, "dynamics.py")
+    with contextlib.redirect_stdout(_sink):
+        exec(compile(src, mod.__file__, "exec"), mod.__dict__)
+    rng = np.random.default_rng(12)
+    L, H, W = 5, 12, 20
+    geom = quiet(geometry.gen_geometry, H, W, L, sig_func=geometry.manabe_sig)
+    p0, u0, v0, t0, q0 = dense_ic(geom, rng)
+    st = (p0 * U.Pa, u0 * MS, v0 * MS, t0 * U.K, q0 * U.dimensionless)
+    out = dict(p0=p0, u0=u0, v0=v0, t0=t0, q0=q0, dt=300.0)
+    dut, dvt = mod.advec_m_pu(st[0], st[1], st[2], dynamics.calc_pu(st[0], st[1]),
+                              dynamics.calc_pv(st[0], st[2]), geom)
+    out["dut"], out["dvt"] = m(dut), m(dvt)
+    for n in (1, 2):
+        st = quiet(mod.matsuno_timestep, *st, 300.0 * U.s, geom)
+        for k, val in zip("puvtq", st):
+            out["step%d_%s" % (n, k)] = m(val)
+    save("g12_coriolis", **out)
+
+
 if __name__ == "__main__":
     for f in (g1_shifts, g2_sw2d, g3_sw2d_temp, g4_tracer, g5_geometry, g6_lowpass,
-              g7_half_step, g8_pe25d, g9_oned, g10_pe2d, g11_temperature):
+              g7_half_step, g8_pe25d, g9_oned, g10_pe2d, g11_temperature, g12_coriolis):
         f()

@@ -304,3 +304,19 @@ def test_g11_temperature_and_constants():
     same(temperature.to_density(d["tt"], d["p"]), d["rho"])
     for k in ("kappa", "P0", "G", "Rd", "Cp", "radius", "Rv"):
         assert getattr(constants, k) == float(d[k]), k
+
+
+def test_g12_coriolis_branch():
+    """the disabled Coriolis branch (dynamics.py:83-92), reference run with `if False` flipped in
+    memory by make_golden.g12_coriolis"""
+    d = golden("g12_coriolis")
+    L, H, W = d["u0"].shape
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    st = tuple(d[k + "0"] for k in "puvtq")
+    dut, dvt = dynamics.advec_m_pu(st[0], st[1], st[2], dynamics.calc_pu(st[0], st[1]),
+                                   dynamics.calc_pv(st[0], st[2]), geom, coriolis=True)
+    same(dut, d["dut"]); same(dvt, d["dvt"])
+    for n in (1, 2):
+        st = dynamics.matsuno_timestep(*st, float(d["dt"]), geom, coriolis=True)
+        for k, x in zip("puvtq", st):
+            same(x, d["step%d_%s" % (n, k)])

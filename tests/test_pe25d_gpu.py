@@ -209,3 +209,18 @@ def test_checkpoint_resume_bit_exact(g, tmp_path):
     for x, y in zip(b.get_state(), want):
         assert np.array_equal(x, y)
     b.close()
+
+
+def test_coriolis_option_vs_golden(g):
+    """optional Coriolis terms (dynamics.py:82-92, off in the reference) vs the reference's own
+    expressions run with the switch flipped (G12)"""
+    from gcmiipy_amd import geometry, dynamics
+    d = golden("g12_coriolis")
+    L, H, W = d["u0"].shape
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    st = [d[k + "0"] for k in "puvtq"]
+    for n in (1, 2):
+        st = dynamics.matsuno_timestep(*st, float(d["dt"]), geom, coriolis=True)
+        _check(st, [d["step%d_%s" % (n, k)] for k in "puvtq"], "coriolis step %d" % n)
+    off = dynamics.matsuno_timestep(*[d[k + "0"] for k in "puvtq"], float(d["dt"]), geom)
+    assert rel_err(off[1], d["step1_u"]) > 1e-6          # the terms do change the answer
