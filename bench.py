@@ -197,8 +197,17 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
             else:
                 kname, kms = "sw2d_stage_kernel (corrector stage)", kiso
             ach = cells * bpc / launches / (kms * 1e-3) / 1e9
+            # HBM bytes per launch from the rocprofv3 PMC passes of this same command (separate
+            # FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied): profiles/r01/traffic.json,
+            # written by tools_prof.sh + tools_traffic.py; null if that file is absent
+            traffic = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
+                traffic = tj[name][("gcm::" + kname.split(" ")[0])]["hbm_bytes_per_launch"]
+            except Exception:
+                pass
             res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                                "kernel_ms": kms, "kernel_ms_isolated": kiso,
                                "algorithmic_bytes_per_launch": cells * bpc / launches}
         core.close()
