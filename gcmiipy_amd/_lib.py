@@ -54,6 +54,10 @@ SYMBOLS = {
     "gcm_set_star": (C.c_int, [_H] + [C.c_void_p] * 5),
     "gcm_diag": (C.c_int, [_H, C.c_int, _dp]),
     "gcm_energy": (C.c_int, [_H, _dp, C.c_int, _dp]),
+    "gcm_set_ground": (C.c_int, [_H, C.c_void_p]),
+    "gcm_get_ground": (C.c_int, [_H, C.c_void_p]),
+    "gcm_grey_radiation": (C.c_int, [_H] + [C.c_double] * 4 + [_dp, _dp, C.c_void_p, C.c_void_p]),
+    "gcm_solar_step": (C.c_int, [_H] + [C.c_double] * 5 + [_dp, _dp]),
     "gcm_halo_bytes": (C.c_size_t, [_H]),
     "gcm_halo_pack": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
     "gcm_halo_unpack": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),

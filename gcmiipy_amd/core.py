@@ -154,6 +154,33 @@ class Core:
         _check(lib.gcm_energy(self._h, _tab(a), a.size, out), self._h)
         return tuple(out)
 
+    # -- column physics (GCM_PE25D) ----------------------------------------------------
+    def set_ground(self, gt):
+        _check(lib.gcm_set_ground(self._h, _ptr(as_f64(gt, (self.H, self.W), "gt"))), self._h)
+
+    def get_ground(self):
+        out = np.empty((self.H, self.W))
+        _check(lib.gcm_get_ground(self._h, _ptr(out)), self._h)
+        return out
+
+    def _latlon(self, geom):
+        lat = as_f64(np.asarray(geom.lat, dtype=np.float64).reshape(-1), name="lat")
+        lon = as_f64(np.asarray(geom.long, dtype=np.float64).reshape(-1), (self.W,), "long")
+        return lat, lon
+
+    def grey_radiation(self, geom, utc, t_lw=0.1, t_sw=0.9, albedo=0.3):
+        """-> (dTdt [L,H,W], dt_ground [H,W]), grey_solar.basic_grey_radiation"""
+        lat, lon = self._latlon(geom)
+        dT, dg = np.empty((self.L, self.H, self.W)), np.empty((self.H, self.W))
+        _check(lib.gcm_grey_radiation(self._h, float(utc), t_lw, t_sw, albedo, _tab(lat), _tab(lon),
+                                      _ptr(dT), _ptr(dg)), self._h)
+        return dT, dg
+
+    def solar_step(self, geom, dt, utc, t_lw=0.1, t_sw=0.9, albedo=0.3):
+        lat, lon = self._latlon(geom)
+        _check(lib.gcm_solar_step(self._h, float(dt), float(utc), t_lw, t_sw, albedo, _tab(lat),
+                                  _tab(lon)), self._h)
+
     def time_steps(self, nsteps, dt, per_kernel=True):
         ms, kms = C.c_double(), C.c_double()
         _check(lib.gcm_time_steps(self._h, int(nsteps), float(dt), C.byref(ms),

@@ -614,6 +614,34 @@ int gcm_energy(gcm_handle *h, const double *area, int area_len, double *out4) {
     return rc;
 }
 
+int gcm_set_ground(gcm_handle *h, const double *gt) {
+    if (!h || !gt) return GCM_ERR_ARG;
+    if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_set_ground: GCM_PE25D only");
+    return pe25d_ground(h->pe, true, gt, nullptr, &h->err);
+}
+
+int gcm_get_ground(gcm_handle *h, double *gt) {
+    if (!h || !gt) return GCM_ERR_ARG;
+    if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_get_ground: GCM_PE25D only");
+    return pe25d_ground(h->pe, false, nullptr, gt, &h->err);
+}
+
+int gcm_grey_radiation(gcm_handle *h, double utc, double t_lw, double t_sw, double albedo,
+                       const double *lat, const double *lon, double *dTdt, double *dt_ground) {
+    if (!h) return GCM_ERR_ARG;
+    if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_grey_radiation: GCM_PE25D only");
+    return pe25d_radiation(h->pe, false, 0.0, utc, t_lw, t_sw, albedo, lat, lon, dTdt, dt_ground,
+                           h->stream, &h->err);
+}
+
+int gcm_solar_step(gcm_handle *h, double dt, double utc, double t_lw, double t_sw, double albedo,
+                   const double *lat, const double *lon) {
+    if (!h) return GCM_ERR_ARG;
+    if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_solar_step: GCM_PE25D only");
+    return pe25d_radiation(h->pe, true, dt, utc, t_lw, t_sw, albedo, lat, lon, nullptr, nullptr,
+                           h->stream, &h->err);
+}
+
 int gcm_time_steps(gcm_handle *h, int nsteps, double dt, double *ms, double *kernel_ms_avg) {
     if (!h || nsteps < 1 || !ms) return GCM_ERR_ARG;
     hipEvent_t e0, e1;

@@ -23,6 +23,10 @@ int pe25d_step_part(Pe25d *m, int part, double dt, hipStream_t s, std::string *e
 int pe25d_half(Pe25d *m, int stage, double dt, hipStream_t s, std::string *err);
 size_t pe25d_halo_bytes(const Pe25d *m);
 int pe25d_halo(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s, std::string *err);
+int pe25d_ground(Pe25d *m, bool set, const double *in, double *out, std::string *err);
+int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, double t_sw, double albedo,
+                    const double *lat, const double *lon, double *dTdt_host, double *dtg_host,
+                    hipStream_t s, std::string *err);
 int pe25d_energy(Pe25d *m, const double *area_host, int area_len, double out[4], std::string *err);
 const double *pe25d_field(Pe25d *m, int field, long *n);
 void pe25d_timing(Pe25d *m, std::vector<hipEvent_t> *ev, size_t *used);

@@ -530,6 +530,72 @@ __global__ __launch_bounds__(256) void pe_energy_kernel(PeArgs a, const double *
     }
 }
 
+// ---------------------------------------------------------------- grey radiation (column physics)
+// basic_grey_radiation (grey_solar.py:358-563) + solar_timestep (no_limits_2_5d.py:66-75):
+// one thread per (j,i) column, the upwelling scan bottom-up, the downwelling scan top-down.
+struct RadArgs {
+    const double *tlw, *tsw, *csw_top, *clw_b_div, *swfac;   // [L] level tables (host-built)
+    const double *coslat, *sinlat, *lon;                     // [Hg], [Hg], [W]
+    double *gt;                                              // ground temperature [H][W]
+    double *emis, *lwb, *ttp;                                // 3-D scratch (parked per level)
+    double *dTdt, *dtg;                                      // tendencies out (3-D, 2-D scratch)
+    double hour_angle, albedo, dt;
+    int apply;                                               // 1: t, gt updated in place
+};
+
+__global__ __launch_bounds__(256) void pe_radiation_kernel(PeArgs a, RadArgs r, double *t_inout) {
+    __shared__ double tab[kExnerTabDoubles];
+    tab[threadIdx.x] = a.exner_tab[threadIdx.x];
+    __syncthreads();
+    constexpr double kSolar = 1.3608 * 1000.0, kSb = 5.67e-8, kCg = 1.13e6;   // constants.py:59,71,25
+    const int W = a.W, L = a.L;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= W) return;
+    const int jg = wrapi(a.row0 + j, a.Hg);
+    const long c3 = (long)j * L * W + i, c2 = (long)j * W + i;
+    const double pc = a.p[c2], gt = r.gt[c2];
+    // zenith_angle, grey_solar.py:49-65 (declination 0)
+    const double pa = r.lon[i] + r.hour_angle;
+    const double sza = fmax(r.sinlat[jg] * 0.0 + r.coslat[jg] * 1.0 * cos(pa), 0.0);
+    const double Sc = kSolar * sza;
+    const double S = (1 - r.albedo) * Sc * r.csw_top[0];
+    const double g2 = gt * gt;
+    const double U_s = 1 * kSb * (g2 * g2);
+    double B = 0.0, up = 0.0;
+    for (int k = 0; k < L; ++k) {                            // bottom-up: emission, B, LWA_b
+        const long o = c3 + (long)k * W;
+        const double tp = pc * a.sig[k] + a.ptop;
+        const double tt = t_inout[o] * exner(tp, tab);       // to_true_temp
+        const double t2 = tt * tt;
+        const double em = (1 - r.tlw[k]) * kSb * (t2 * t2);
+        B += em * r.clw_b_div[k];
+        r.lwb[o] = up * (1 - r.tlw[k]);
+        up = up * r.tlw[k] + em;
+        r.emis[o] = em;
+        r.ttp[o] = tt;
+    }
+    const double dtg = (B + S - U_s) / kCg / (.1);
+    r.dtg[c2] = dtg;
+    if (r.apply) r.gt[c2] = gt + dtg * r.dt;
+    double down = 0.0;
+    for (int k = L - 1; k >= 0; --k) {                       // top-down: LWA_a, then eq. 2.34
+        const long o = c3 + (long)k * W;
+        const double em = r.emis[o];
+        const double lwa = down * (1 - r.tlw[k]);
+        down = down * r.tlw[k] + em;
+        const double U_n = r.clw_b_div[k] * U_s * (1 - r.tlw[k]);
+        const double S_n = r.swfac[k] * Sc;
+        const double dTdt = (U_n + S_n - 2 * em + lwa + r.lwb[o]) * (kG / (kCp * pc * a.dsig[k]));
+        r.dTdt[o] = dTdt;
+        if (r.apply) {
+            const double tp = pc * a.sig[k] + a.ptop;
+            const double tt_n = r.ttp[o] + dTdt * r.dt;
+            t_inout[o] = tt_n * rcp(exner(tp, tab));          // to_potential_temp
+        }
+    }
+}
+
 // ---------------------------------------------------------------- layout transposes
 // host layout [k][j][i] (rows of THIS band only) <-> device [j][k][i]
 __global__ void pe_to_device_kernel(double *dst, const double *src, int W, int H, int L) {
@@ -569,6 +635,10 @@ struct Pe25d {
            *smul = nullptr, *exner_tab = nullptr;
     double2 *tw = nullptr;
     FftPlan plan{};
+    double *gt = nullptr;                       // ground temperature [H][W] (column physics)
+    double *rad_tab = nullptr;                  // 5 x [L] level tables of the last radiation call
+    double *rad_geo = nullptr;                  // coslat[Hg], sinlat[Hg], lon[W]
+    double rad_key[2] = {-1.0, -1.0};           // (t_lw, t_sw) the level tables were built for
     std::vector<hipEvent_t> *ev = nullptr;
     size_t *ev_used = nullptr;
 };
@@ -917,6 +987,88 @@ int pe25d_halo(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s, std:
     if (hipGetLastError() != hipSuccess) {
         *err = "hip: pe25d halo copy launch failed";
         return GCM_ERR_HIP;
+    }
+    return GCM_OK;
+}
+
+int pe25d_ground(Pe25d *m, bool set, const double *in, double *out, std::string *err) {
+    const size_t bytes = sizeof(double) * (size_t)m->H * m->W;
+    (void)hipDeviceSynchronize();
+    if (!m->gt) {
+        void *d = nullptr;
+        if (hipMalloc(&d, bytes) != hipSuccess || hipMemset(d, 0, bytes) != hipSuccess) {
+            *err = "hip: ground temperature allocation failed";
+            return GCM_ERR_HIP;
+        }
+        m->allocs.push_back(d);
+        m->gt = (double *)d;
+    }
+    hipError_t e = set ? hipMemcpy(m->gt, in, bytes, hipMemcpyHostToDevice)
+                       : hipMemcpy(out, m->gt, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { *err = "hip: ground temperature transfer failed"; return GCM_ERR_HIP; }
+    return GCM_OK;
+}
+
+// basic_grey_radiation (+ optional in-place solar_timestep).  dTdt_host / dtg_host may be null.
+int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, double t_sw, double albedo,
+                    const double *lat, const double *lon, double *dTdt_host, double *dtg_host,
+                    hipStream_t s, std::string *err) {
+    if (!m->gt) { *err = "radiation: set the ground temperature first (gcm_set_ground)"; return GCM_ERR_STATE; }
+    if (!lat || !lon) { *err = "radiation: lat and lon tables are required"; return GCM_ERR_ARG; }
+    const int W = m->W, H = m->H, L = m->L, Hg = m->Hg;
+    (void)hipDeviceSynchronize();
+    if (m->rad_key[0] != t_lw || m->rad_key[1] != t_sw || !m->rad_tab) {
+        // level tables, same expression order as grey_solar.py:323-333,377-385,541
+        std::vector<double> T((size_t)5 * L), dsig(L);
+        if (hipMemcpy(dsig.data(), m->dsig, sizeof(double) * L, hipMemcpyDeviceToHost) != hipSuccess) {
+            *err = "hip: radiation table read-back failed"; return GCM_ERR_HIP;
+        }
+        double *tlw = T.data(), *tsw = tlw + L, *csw = tsw + L, *cdiv = csw + L, *swf = cdiv + L;
+        for (int k = 0; k < L; ++k) {
+            tlw[k] = 1 - (1 - std::pow(t_lw, dsig[k]));
+            tsw[k] = 1 - (1 - std::pow(t_sw, dsig[k]));
+        }
+        double c = 1.0;
+        for (int k = L - 1; k >= 0; --k) { c = k == L - 1 ? tsw[k] : c * tsw[k]; csw[k] = c; }
+        for (int k = 0; k < L; ++k) { c = k == 0 ? tlw[k] : c * tlw[k]; cdiv[k] = c / tlw[k]; }
+        for (int k = 0; k < L; ++k) swf[k] = (1 - tsw[k]) * csw[k] / tsw[k];
+        if (!m->rad_tab && !dev_upload<double>(m, &m->rad_tab, nullptr, (size_t)5 * L)) {
+            *err = "hip: radiation table allocation failed"; return GCM_ERR_HIP;
+        }
+        if (hipMemcpy(m->rad_tab, T.data(), sizeof(double) * 5 * L, hipMemcpyHostToDevice) != hipSuccess) {
+            *err = "hip: radiation table upload failed"; return GCM_ERR_HIP;
+        }
+        m->rad_key[0] = t_lw; m->rad_key[1] = t_sw;
+    }
+    {
+        std::vector<double> Gt((size_t)2 * Hg + W);
+        for (int j = 0; j < Hg; ++j) { Gt[j] = std::cos(lat[j]); Gt[Hg + j] = std::sin(lat[j]); }
+        for (int i = 0; i < W; ++i) Gt[2 * Hg + i] = lon[i];
+        if (!m->rad_geo && !dev_upload<double>(m, &m->rad_geo, nullptr, Gt.size())) {
+            *err = "hip: radiation geometry allocation failed"; return GCM_ERR_HIP;
+        }
+        if (hipMemcpy(m->rad_geo, Gt.data(), sizeof(double) * Gt.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            *err = "hip: radiation geometry upload failed"; return GCM_ERR_HIP;
+        }
+    }
+    PeArgs a = make_args(m, m->cur_i, m->cur_i, dt);
+    RadArgs r{};
+    r.tlw = m->rad_tab; r.tsw = r.tlw + L; r.csw_top = r.tsw + L; r.clw_b_div = r.csw_top + L; r.swfac = r.clw_b_div + L;
+    r.coslat = m->rad_geo; r.sinlat = m->rad_geo + Hg; r.lon = m->rad_geo + 2 * Hg;
+    r.gt = m->gt;
+    r.emis = m->spu; r.lwb = m->phi; r.ttp = m->rho; r.dTdt = m->pgfu; r.dtg = m->pit;
+    r.hour_angle = utc / (-24 * 3600.0) * 360 * (M_PI / 180);      // grey_solar.py:51
+    r.albedo = albedo; r.dt = dt; r.apply = apply ? 1 : 0;
+    hipLaunchKernelGGL(pe_radiation_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, a, r, m->st[m->cur_i][GCM_T]);
+    if (hipStreamSynchronize(s) != hipSuccess) { *err = "hip: radiation kernel failed"; return GCM_ERR_HIP; }
+    if (dtg_host && hipMemcpy(dtg_host, m->pit, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost) != hipSuccess) {
+        *err = "hip: dt_ground copy-back failed"; return GCM_ERR_HIP;
+    }
+    if (dTdt_host) {
+        hipLaunchKernelGGL(pe_to_host_kernel, dim3(1024), dim3(256), 0, nullptr, m->stage3, m->pgfu, W, H, L);
+        if (hipMemcpy(dTdt_host, m->stage3, sizeof(double) * (size_t)H * W * L, hipMemcpyDeviceToHost) != hipSuccess) {
+            *err = "hip: dTdt copy-back failed"; return GCM_ERR_HIP;
+        }
     }
     return GCM_OK;
 }

@@ -159,6 +159,20 @@ int gcm_diag(gcm_handle *h, int kind, double *out);
  * axis (:49), so area_len must be W (== H) or 1 -- reproduced, not fixed.                      */
 int gcm_energy(gcm_handle *h, const double *area, int area_len, double *out4);
 
+/* Column physics next to the dynamics (GCM_PE25D).  The ground temperature
+ * gt[H][W] (GroundVars.gt, no_limits_2_5d.py:143) lives in the handle.  `lat` [global_height]
+ * and `lon` [W] are geom.lat / geom.long in radians; `utc` in seconds.
+ *   gcm_grey_radiation  grey_solar.basic_grey_radiation(p,tp,tt,g,t_lw,t_sw,albedo,utc,geom)
+ *                       -> dTdt [L][H][W], dt_ground [H][W] (either may be NULL)  grey_solar.py:358-563
+ *   gcm_solar_step      no_limits_2_5d.solar_timestep: theta and gt advanced in place by dt
+ *                       (the reference passes t_lw = 0.1, t_sw = 0.9, albedo = 0.3)  no_limits_2_5d.py:66-75 */
+int gcm_set_ground(gcm_handle *h, const double *gt);
+int gcm_get_ground(gcm_handle *h, double *gt);
+int gcm_grey_radiation(gcm_handle *h, double utc, double t_lw, double t_sw, double albedo,
+                       const double *lat, const double *lon, double *dTdt, double *dt_ground);
+int gcm_solar_step(gcm_handle *h, double dt, double utc, double t_lw, double t_sw, double albedo,
+                   const double *lat, const double *lon);
+
 /* Latitude-band ghost rows (nranks > 1).  The library packs the rows a neighbour
  * needs into / unpacks them from caller-owned DEVICE buffers (e.g. torch tensors
  * handed to torch.distributed / RCCL send-recv); it never calls a collective

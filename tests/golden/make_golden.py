@@ -477,7 +477,27 @@ def g12_coriolis():
     save("g12_coriolis", **out)
 
 
+def g13_radiation():
+    """grey_solar.basic_grey_radiation and no_limits_2_5d.solar_timestep on a dense state"""
+    import grey_solar
+    rng = np.random.default_rng(13)
+    L, H, W = 5, 12, 20
+    geom = quiet(geometry.gen_geometry, H, W, L, sig_func=geometry.manabe_sig)
+    p0, u0, v0, t0, q0 = dense_ic(geom, rng)
+    gt0 = 290 + 5 * rng.standard_normal((H, W))
+    out = dict(p0=p0, t0=t0, gt0=gt0, dt=900.0)
+    g = no_limits_2_5d.GroundVars(gt0 * U.K, None, None, None)
+    for tag, utc in (("a", 0.0), ("b", 7.5 * 3600.0)):
+        tp = p0 * U.Pa * geom.sig + geom.ptop
+        tt = temperature.to_true_temp(t0 * U.K, tp)
+        dTdt, dtg = quiet(grey_solar.basic_grey_radiation, p0 * U.Pa, tp, tt, g, 0.1, 0.9, 0.3, utc * U.s, geom)
+        t_n, g_n = quiet(no_limits_2_5d.solar_timestep, t0 * U.K, p0 * U.Pa, g, 900.0 * U.s, utc * U.s, geom)
+        out.update({"utc_" + tag: utc, "dTdt_" + tag: m(dTdt), "dtg_" + tag: m(dtg), "t_n_" + tag: m(t_n),
+                    "gt_n_" + tag: m(g_n.gt), "sza_" + tag: m(grey_solar.zenith_angle(geom.long, geom.lat, utc * U.s, geom))})
+    save("g13_radiation", **out)
+
+
 if __name__ == "__main__":
     for f in (g1_shifts, g2_sw2d, g3_sw2d_temp, g4_tracer, g5_geometry, g6_lowpass,
-              g7_half_step, g8_pe25d, g9_oned, g10_pe2d, g11_temperature, g12_coriolis):
+              g7_half_step, g8_pe25d, g9_oned, g10_pe2d, g11_temperature, g12_coriolis, g13_radiation):
         f()

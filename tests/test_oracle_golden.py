@@ -320,3 +320,20 @@ def test_g12_coriolis_branch():
         st = dynamics.matsuno_timestep(*st, float(d["dt"]), geom, coriolis=True)
         for k, x in zip("puvtq", st):
             same(x, d["step%d_%s" % (n, k)])
+
+
+def test_g13_radiation():
+    from oracle import physics
+    d = golden("g13_radiation")
+    L, H, W = d["t0"].shape
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    p, t, gt = d["p0"], d["t0"], d["gt0"]
+    for tag in "ab":
+        utc = float(d["utc_" + tag])
+        same(physics.zenith_angle(geom.long, geom.lat, utc, geom), d["sza_" + tag])
+        tp = p * geom.sig + geom.ptop
+        tt = temperature.to_true_temp(t, tp)
+        dTdt, dtg = physics.basic_grey_radiation(p, tp, tt, gt, 0.1, 0.9, 0.3, utc, geom)
+        same(dTdt, d["dTdt_" + tag]); same(dtg, d["dtg_" + tag])
+        t_n, gt_n = physics.solar_timestep(t, p, gt, float(d["dt"]), utc, geom)
+        same(t_n, d["t_n_" + tag]); same(gt_n, d["gt_n_" + tag])

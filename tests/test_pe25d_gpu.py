@@ -224,3 +224,24 @@ def test_coriolis_option_vs_golden(g):
         _check(st, [d["step%d_%s" % (n, k)] for k in "puvtq"], "coriolis step %d" % n)
     off = dynamics.matsuno_timestep(*[d[k + "0"] for k in "puvtq"], float(d["dt"]), geom)
     assert rel_err(off[1], d["step1_u"]) > 1e-6          # the terms do change the answer
+
+
+def test_grey_radiation_and_solar_timestep(g):
+    """column physics vs values captured from grey_solar.basic_grey_radiation and
+    no_limits_2_5d.solar_timestep (G13)"""
+    from gcmiipy_amd import geometry, grey_solar
+    d = golden("g13_radiation")
+    L, H, W = d["t0"].shape
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    p, t, gt = d["p0"], d["t0"], d["gt0"]
+    gv = grey_solar.GroundVars(gt, None, None, None)
+    tp = p * geom.sig + geom.ptop
+    tt = t / ((1e5 / tp) ** (287.0 / 1004.0))
+    for tag in "ab":
+        utc = float(d["utc_" + tag])
+        dTdt, dtg = grey_solar.basic_grey_radiation(p, tp, tt, gv, 0.1, 0.9, 0.3, utc, geom)
+        assert rel_err(dTdt, d["dTdt_" + tag]) < TOL
+        assert rel_err(dtg, d["dtg_" + tag]) < TOL
+        t_n, g_n = grey_solar.solar_timestep(t, p, gv, float(d["dt"]), utc, geom)
+        assert rel_err(t_n, d["t_n_" + tag]) < TOL
+        assert rel_err(g_n.gt, d["gt_n_" + tag]) < TOL
