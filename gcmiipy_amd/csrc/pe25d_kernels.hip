@@ -29,6 +29,7 @@ struct FftPlan {
     int n, nrad;
     int rad[kMaxRadices];
     unsigned magic[kMaxRadices];   // ceil(2^32 / Ns) per pass: b / Ns == umulhi(b, magic) for b*Ns < 2^32
+    int inplace;                   // 1: only radices 2,3,4,5 and N/2 <= kMaxBfly*256: single-buffer passes
 };
 
 struct PeArgs {
@@ -169,6 +170,116 @@ __device__ double2 *fft_lds(double2 *x, double2 *y, const double2 *tw, const Fft
     return x;
 }
 
+// ---- in-place variant for {2,3,4,5}-smooth lengths: every thread pulls the inputs of its (at
+// most kMaxBfly) butterflies into registers, the workgroup synchronises, and the outputs go back
+// into the SAME buffer.  Half the LDS of the ping-pong form, so twice the workgroups per CU.
+constexpr int kMaxBfly = 3;    // ceil((N / 2) / blockDim) for N <= 1536 at 256 threads
+
+template <int R, bool INV>
+__device__ __forceinline__ void butterfly(double2 (&v)[R]) {
+    if (R == 2) {
+        const double2 a0 = v[0], a1 = v[1];
+        v[0] = cadd(a0, a1);
+        v[1] = csub(a0, a1);
+    } else if (R == 4) {
+        const double2 s02 = cadd(v[0], v[2]), d02 = csub(v[0], v[2]);
+        const double2 s13 = cadd(v[1], v[3]), jd = rot<INV>(csub(v[1], v[3]));
+        v[0] = cadd(s02, s13);
+        v[1] = cadd(d02, jd);
+        v[2] = csub(s02, s13);
+        v[3] = csub(d02, jd);
+    } else if (R == 3) {
+        const double2 t = cadd(v[1], v[2]);
+        const double2 m = make_double2(v[0].x - 0.5 * t.x, v[0].y - 0.5 * t.y);
+        double2 sv = rot<INV>(csub(v[1], v[2]));
+        sv.x *= 0.86602540378443864676;
+        sv.y *= 0.86602540378443864676;
+        v[0] = cadd(v[0], t);
+        v[1] = cadd(m, sv);
+        v[2] = csub(m, sv);
+    } else {   // R == 5
+        constexpr double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
+        constexpr double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
+        const double2 a0 = v[0];
+        const double2 p1 = cadd(v[1], v[4]), p2 = cadd(v[2], v[3]), q1 = csub(v[1], v[4]), q2 = csub(v[2], v[3]);
+        const double2 m1 = make_double2(a0.x + c1 * p1.x + c2 * p2.x, a0.y + c1 * p1.y + c2 * p2.y);
+        const double2 m2 = make_double2(a0.x + c2 * p1.x + c1 * p2.x, a0.y + c2 * p1.y + c1 * p2.y);
+        const double2 n1 = rot<INV>(make_double2(s1 * q1.x + s2 * q2.x, s1 * q1.y + s2 * q2.y));
+        const double2 n2 = rot<INV>(make_double2(s2 * q1.x - s1 * q2.x, s2 * q1.y - s1 * q2.y));
+        v[0] = cadd(a0, cadd(p1, p2));
+        v[1] = cadd(m1, n1);
+        v[2] = cadd(m2, n2);
+        v[3] = csub(m2, n2);
+        v[4] = csub(m1, n1);
+    }
+}
+
+template <int R, bool INV>
+__device__ __forceinline__ void pass_inplace(double2 *x, const double2 *tw, int N, int Ns, unsigned magic) {
+    const int nb = N / R;
+    const int tstep = N / (Ns * R);
+    double2 v[kMaxBfly][R];
+    int j0[kMaxBfly];
+#pragma unroll
+    for (int n = 0; n < kMaxBfly; ++n) {
+        const int b = threadIdx.x + n * blockDim.x;
+        if (b < nb) {
+            const int blk = Ns == 1 ? b : (int)__umulhi((unsigned)b, magic);
+            const int k = b - blk * Ns;
+            j0[n] = blk * Ns * R + k;
+            const int t1 = k * tstep;
+            v[n][0] = x[b];
+#pragma unroll
+            for (int m = 1; m < R; ++m) v[n][m] = cmul(x[b + m * nb], twid<INV>(tw, m * t1));
+            butterfly<R, INV>(v[n]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < kMaxBfly; ++n) {
+        const int b = threadIdx.x + n * blockDim.x;
+        if (b < nb) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) x[j0[n] + q * Ns] = v[n][q];
+        }
+    }
+    __syncthreads();
+}
+
+template <bool INV>
+__device__ void fft_inplace(double2 *x, const double2 *tw, const FftPlan &P) {
+    int Ns = 1;
+    for (int pass = 0; pass < P.nrad; ++pass) {
+        const int r = P.rad[pass];
+        const unsigned magic = P.magic[pass];
+        if (r == 4) pass_inplace<4, INV>(x, tw, P.n, Ns, magic);
+        else if (r == 2) pass_inplace<2, INV>(x, tw, P.n, Ns, magic);
+        else if (r == 3) pass_inplace<3, INV>(x, tw, P.n, Ns, magic);
+        else pass_inplace<5, INV>(x, tw, P.n, Ns, magic);
+        Ns *= r;
+    }
+}
+
+// in-place filter of the two rows packed in x[0..N); result left in x, scaled by 1/N
+__device__ void filter_rows_inplace(double2 *x, const PeArgs &a, int jglob) {
+    const int N = a.W;
+    fft_inplace<false>(x, a.tw, a.plan);
+    const double *S = a.smul + (long)jglob * (N / 2 + 1);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const double s = S[n <= N / 2 ? n : N - n];
+        x[n].x *= s;
+        x[n].y *= s;
+    }
+    __syncthreads();
+    fft_inplace<true>(x, a.tw, a.plan);
+    const double inv_n = 1.0 / (double)N;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        x[n].x *= inv_n;
+        x[n].y *= inv_n;
+    }
+    __syncthreads();
+}
+
 // filter two real rows held as re/im of x[0..N): FFT, multiply by S[n] (n folded), inverse FFT.
 // Returns the buffer holding the result (already scaled by 1/N).
 __device__ double2 *filter_rows(double2 *x, double2 *y, const PeArgs &a, int jglob) {
@@ -211,7 +322,10 @@ __global__ __launch_bounds__(256) void pe_spu_filter_kernel(PeArgs a) {
     }
     __syncthreads();
     double2 *res = x;
-    if (a.filter && W > 1) res = filter_rows(x, y, a, wrapi(a.row0 + j, a.Hg));
+    if (a.filter && W > 1) {
+        if (a.plan.inplace) filter_rows_inplace(x, a, wrapi(a.row0 + j, a.Hg));
+        else res = filter_rows(x, y, a, wrapi(a.row0 + j, a.Hg));
+    }
     double *o0 = a.spu + ix.r3(j) + (long)k0 * W;
     for (int i = threadIdx.x; i < W; i += blockDim.x) {
         o0[i] = res[i].x;
@@ -326,7 +440,10 @@ __global__ __launch_bounds__(256) void pe_pgf_filter_kernel(PeArgs a) {
     }
     __syncthreads();
     double2 *res = x;
-    if (a.filter && W > 1) res = filter_rows(x, y, a, jg);
+    if (a.filter && W > 1) {
+        if (a.plan.inplace) filter_rows_inplace(x, a, jg);
+        else res = filter_rows(x, y, a, jg);
+    }
     double *out = a.pgfu + o0;
     for (int i = threadIdx.x; i < W; i += blockDim.x) {
         out[i] = res[i].x;
@@ -657,6 +774,9 @@ static bool make_plan(int n, FftPlan *P) {
         P->magic[i] = (unsigned)(((1ULL << 32) + (unsigned long long)Ns - 1) / (unsigned long long)Ns);
         Ns *= P->rad[i];
     }
+    P->inplace = (n / 2 <= 3 * 256) ? 1 : 0;
+    for (int i = 0; i < P->nrad; ++i)
+        if (P->rad[i] > 5) P->inplace = 0;
     return m == 1 && P->nrad <= kMaxRadices;
 }
 
@@ -880,7 +1000,7 @@ static void half(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1
     PeArgs a = make_args(m, stage_set, out_set, dt);
     const int W = m->W, L = m->L;
     const int ext = m->wrap ? 0 : 1;             // intermediates are also needed on row j1 (south)
-    const size_t lds = (size_t)2 * W * sizeof(double2);
+    const size_t lds = (size_t)(m->plan.inplace ? 1 : 2) * W * sizeof(double2);
     const int pairs = (L + 1) / 2;
     a.j0 = j0;
     a.j1 = j1 + ext;
