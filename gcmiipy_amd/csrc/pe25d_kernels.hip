@@ -173,7 +173,8 @@ __device__ double2 *fft_lds(double2 *x, double2 *y, const double2 *tw, const Fft
 // ---- in-place variant for {2,3,4,5}-smooth lengths: every thread pulls the inputs of its (at
 // most kMaxBfly) butterflies into registers, the workgroup synchronises, and the outputs go back
 // into the SAME buffer.  Half the LDS of the ping-pong form, so twice the workgroups per CU.
-constexpr int kMaxBfly = 3;    // ceil((N / 2) / blockDim) for N <= 1536 at 256 threads
+constexpr int kFftThreads = 512;
+constexpr int kMaxBfly = 2;    // ceil((N / 2) / kFftThreads) for N <= 1536
 
 template <int R, bool INV>
 __device__ __forceinline__ void butterfly(double2 (&v)[R]) {
@@ -304,7 +305,7 @@ __device__ double2 *filter_rows(double2 *x, double2 *y, const PeArgs &a, int jgl
 }
 
 // ---------------------------------------------------------------- K1: spu = filter(su * iph(sp))
-__global__ __launch_bounds__(256) void pe_spu_filter_kernel(PeArgs a) {
+__global__ __launch_bounds__(kFftThreads) void pe_spu_filter_kernel(PeArgs a) {
     extern __shared__ double2 lds[];
     double2 *x = lds, *y = lds + a.W;
     const Idx ix{a.W, a.H, a.L, a.wrap};
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(kColThreads) void pe_column_kernel(PeArgs a) {
 }
 
 // ---------------------------------------------------------------- K3: pgfu = filter(pgu + phiu)
-__global__ __launch_bounds__(256) void pe_pgf_filter_kernel(PeArgs a) {
+__global__ __launch_bounds__(kFftThreads) void pe_pgf_filter_kernel(PeArgs a) {
     extern __shared__ double2 lds[];
     double2 *x = lds, *y = lds + a.W;
     const Idx ix{a.W, a.H, a.L, a.wrap};
@@ -774,7 +775,7 @@ static bool make_plan(int n, FftPlan *P) {
         P->magic[i] = (unsigned)(((1ULL << 32) + (unsigned long long)Ns - 1) / (unsigned long long)Ns);
         Ns *= P->rad[i];
     }
-    P->inplace = (n / 2 <= 3 * 256) ? 1 : 0;
+    P->inplace = (n / 2 <= kMaxBfly * kFftThreads) ? 1 : 0;
     for (int i = 0; i < P->nrad; ++i)
         if (P->rad[i] > 5) P->inplace = 0;
     return m == 1 && P->nrad <= kMaxRadices;
@@ -1004,14 +1005,14 @@ static void half(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1
     const int pairs = (L + 1) / 2;
     a.j0 = j0;
     a.j1 = j1 + ext;
-    hipLaunchKernelGGL(pe_spu_filter_kernel, dim3(a.j1 - a.j0, pairs), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(pe_spu_filter_kernel, dim3(a.j1 - a.j0, pairs), dim3(kFftThreads), lds, s, a);
     {
         const long tiles = (long)((W + kColThreads - 1) / kColThreads) * (a.j1 - a.j0);
         hipLaunchKernelGGL(pe_column_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kColThreads),
                            sizeof(double) * (size_t)L * kColThreads, s, a);
     }
     a.j1 = j1;
-    hipLaunchKernelGGL(pe_pgf_filter_kernel, dim3(a.j1 - a.j0, pairs), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(pe_pgf_filter_kernel, dim3(a.j1 - a.j0, pairs), dim3(kFftThreads), lds, s, a);
     tick(m, s);
     {
         const long tiles = (long)((W + 255) / 256) * (a.j1 - a.j0);
