@@ -108,8 +108,8 @@ __device__ __forceinline__ double adv_vel_v(double vc, double vw, double ve, dou
 }
 
 // geopotential_gradient_u / _v, matsuno_c_grid.py:97-106: (p[+1] - p) / dx * G
-__device__ __forceinline__ double geo_grad(double p_next, double pc, double inv_dx) {
-    return (p_next - pc) * inv_dx * kG;
+__device__ __forceinline__ double geo_grad(double p_next, double pc, double g_dx) {
+    return (p_next - pc) * g_dx;          // g_dx = G / dx folded on the host
 }
 
 // advection_of_geopotential, matsuno_c_grid.py:109-118
@@ -125,21 +125,25 @@ __device__ __forceinline__ double adv_geo(double uc, double uw, double vc, doubl
 
 // finite_laplacian_2d * mu, viscosity.py:12-25
 __device__ __forceinline__ double visc_u(double uc, double uw, double ue, double un, double us,
-                                         double inv_dx2) {
+                                         double mu_dx2) {
     double top = us + un + ue + uw - 4.0 * uc;
-    return kMuAir * (top * inv_dx2);
+    return top * mu_dx2;                   // mu_dx2 = mu_air / dx^2 folded on the host
 }
 
 // density_from + geopotential_from + scaling, matsumo_temp.py:13-19,28-30,45-47.
 // Returns 1/rho, geo = p/(G rho), scaled_t = p t dx dx.
 struct Thermo { double inv_rho, geo, st; };
-__device__ __forceinline__ Thermo thermo(double p, double t, double dx2, const double *tab) {
+__device__ __forceinline__ Thermo thermo(double p, double t, double dx2, const double *tab,
+                                         double rcp_p) {
     double temp = t * exner(p, tab);           // t / (1e5/p)**kappa
     Thermo r;
-    r.inv_rho = kRd * temp * rcp(p);           // 1 / (p / (Rd T))
+    r.inv_rho = kRd * temp * rcp_p;            // 1 / (p / (Rd T))
     r.geo = temp * (kRd / kG);                 // p / (G rho) = Rd T / G
     r.st = p * t * dx2;
     return r;
+}
+__device__ __forceinline__ Thermo thermo(double p, double t, double dx2, const double *tab) {
+    return thermo(p, t, dx2, tab, rcp(p));
 }
 
 // ---- tracer face flux (two_d.py:103-116,135-149; flux_limiter.py:10-27) -----------
@@ -149,9 +153,10 @@ __device__ __forceinline__ double face_flux(double vel, double qm1, double q0, d
                                             double q2, double dtdx) {
     const bool pos = vel > 0.0;                       // strict >, as flux_limiter.py:24
     // (q0 max(vel,0) + q1 min(vel,0)) dt/dx: one of the two products is a zero
-    const double f_low = (pos ? q0 : q1) * vel * dtdx;
+    const double vd = vel * dtdx;
+    const double f_low = (pos ? q0 : q1) * vd;
     if (!LIMIT) return f_low;
-    const double f_high = vel * (q0 + q1) * (0.5 * dtdx);
+    const double f_high = vd * ((q0 + q1) * 0.5);
     const double b = q1 - q0;
     const double num = pos ? q0 - qm1 : q2 - q1;
     // van_leer(r), r = num / b (0 where b == 0, flux_limiter.py:19):

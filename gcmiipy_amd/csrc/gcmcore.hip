@@ -315,6 +315,9 @@ static Sw2dArgs base_args(gcm_handle *h, double dt) {
     a.inv_dx2 = 1.0 / (h->cfg.dx * h->cfg.dx);
     a.h_dx = 0.5 / h->cfg.dx;
     a.dtdx = dt / h->cfg.dx;
+    a.g_dx = 9.8 / h->cfg.dx;
+    a.mu_dx2 = (18.5 * 1e-6) / (h->cfg.dx * h->cfg.dx);
+    a.inv_dx2_ = a.inv_dx2;
     return a;
 }
 

@@ -24,6 +24,7 @@ struct Sw2dArgs {
     double dt, dx, inv_dx, dx2, inv_dx2;
     double h_dx;                            // 0.5 / dx (exact halving folded in)
     double dtdx;                            // dt / dx
+    double g_dx, mu_dx2, inv_dx2_;          // G / dx, mu_air / dx^2, 1 / dx^2
 };
 
 // staged variant

@@ -75,10 +75,10 @@ __global__ __launch_bounds__(256) void sw2d_stage_kernel(Sw2dArgs a) {
         ge = a.sgeo[rc + ie];
         gs = a.sgeo[rs + i];
     }
-    double du = adv_vel_u(uc, uw, ue, un, us, vc, vw, vs, vsw, a.h_dx) + geo_grad(ge, gc, a.inv_dx);
-    double dv = adv_vel_v(vc, vw, ve, vn, vs, uc, un, uw, usw, a.h_dx) + geo_grad(gs, gc, a.inv_dx);
+    double du = adv_vel_u(uc, uw, ue, un, us, vc, vw, vs, vsw, a.h_dx) + geo_grad(ge, gc, a.g_dx);
+    double dv = adv_vel_v(vc, vw, ve, vn, vs, uc, un, uw, usw, a.h_dx) + geo_grad(gs, gc, a.g_dx);
     if (TEMP) {
-        const double vis = visc_u(uc, uw, ue, un, us, a.inv_dx2) * a.sirho[rc + i];
+        const double vis = visc_u(uc, uw, ue, un, us, a.mu_dx2) * a.sirho[rc + i];
         du -= vis;
         dv -= vis;  // the v equation uses the viscosity of u, matsumo_temp.py:75,91
     }
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void sw2d_stage_kernel(Sw2dArgs a) {
         const double dst = adv_geo(uc, uw, vc, vn, a.sst[rc + i], a.sst[rc + iw], a.sst[rc + ie],
                                    a.sst[rn + i], a.sst[rs + i], a.h_dx);
         const double tt = bp * a.bt[o] * a.dx2 - a.dt * dst;
-        a.ot[o] = tt * rcp(pnew * a.dx2);  // unscaling, matsumo_temp.py:33-35
+        a.ot[o] = tt * (rcp(pnew) * a.inv_dx2);  // unscaling, matsumo_temp.py:33-35
     }
 }
 
@@ -166,13 +166,13 @@ struct Row {
 };
 
 template <bool TEMP>
-__device__ __forceinline__ void make_row(Row &r, double u, double v, double p, double t,
-                                         double dx2, const double *tab) {
+__device__ __forceinline__ void make_row_r(Row &r, double u, double v, double p, double t,
+                                           double dx2, const double *tab, double rcp_p) {
     r.u = u;
     r.v = v;
     r.p = p;
     if (TEMP) {
-        Thermo th = thermo(p, t, dx2, tab);
+        Thermo th = thermo(p, t, dx2, tab, rcp_p);
         r.st = th.st;
         r.g = th.geo;
         r.irho = th.inv_rho;
@@ -183,6 +183,12 @@ __device__ __forceinline__ void make_row(Row &r, double u, double v, double p, d
     }
 }
 
+template <bool TEMP>
+__device__ __forceinline__ void make_row(Row &r, double u, double v, double p, double t,
+                                         double dx2, const double *tab) {
+    make_row_r<TEMP>(r, u, v, p, t, dx2, tab, TEMP ? rcp(p) : 0.0);
+}
+
 struct Tend {
     double du, dv, dp, dst;
 };
@@ -190,7 +196,7 @@ struct Tend {
 // tendencies at the centre row R0 of a 3-row window (north RM, south RP)
 template <bool TEMP>
 __device__ __forceinline__ Tend tendencies(const Row &RM, const Row &R0, const Row &RP,
-                                           double inv_dx, double h_dx, double inv_dx2) {
+                                           double g_dx, double h_dx, double mu_dx2) {
     // i-1 / i+1 neighbours by DPP at the point of use (cheaper than carrying them in VGPRs)
     const double ue = from_east(R0.u), ve = from_east(R0.v);
     const double uw = from_west(R0.u), vw = from_west(R0.v);
@@ -199,11 +205,11 @@ __device__ __forceinline__ Tend tendencies(const Row &RM, const Row &R0, const R
     const double ge = TEMP ? from_east(R0.g) : pe;
     Tend t;
     t.du = adv_vel_u(R0.u, uw, ue, RM.u, RP.u, R0.v, vw, RP.v, vsw, h_dx) +
-           geo_grad(ge, R0.g, inv_dx);
+           geo_grad(ge, R0.g, g_dx);
     t.dv = adv_vel_v(R0.v, vw, ve, RM.v, RP.v, R0.u, RM.u, uw, usw, h_dx) +
-           geo_grad(RP.g, R0.g, inv_dx);
+           geo_grad(RP.g, R0.g, g_dx);
     if (TEMP) {
-        const double vis = visc_u(R0.u, uw, ue, RM.u, RP.u, inv_dx2) * R0.irho;
+        const double vis = visc_u(R0.u, uw, ue, RM.u, RP.u, mu_dx2) * R0.irho;
         t.du -= vis;
         t.dv -= vis;
     }
@@ -246,29 +252,32 @@ struct FusedCtx {
     __device__ __forceinline__ void iter(int r, Row &BM, Row &B0, Row &BP, Row &SN, Row &SM,
                                          Row &S0, Raw &nxt, double &qmm, double &qm, double &q0,
                                          double &qp) {
-        const double dt = a.dt, inv_dx = a.inv_dx, h_dx = a.h_dx, inv_dx2 = a.inv_dx2,
+        const double dt = a.dt, g_dx = a.g_dx, h_dx = a.h_dx, mu_dx2 = a.mu_dx2, inv_dx2 = a.inv_dx2,
                      dx2 = a.dx2;
         // ---- predictor: predicted row r from base rows r-1, r, r+1
         {
-            const Tend t = tendencies<TEMP>(BM, B0, BP, inv_dx, h_dx, inv_dx2);
+            const Tend t = tendencies<TEMP>(BM, B0, BP, g_dx, h_dx, mu_dx2);
             const double us = B0.u - dt * t.du;
             const double vs = B0.v - dt * t.dv;
             const double ps = B0.p - dt * t.dp;
-            double ts = 0.0;
-            if (TEMP) ts = (B0.st - dt * t.dst) * rcp(ps * dx2);
-            make_row<TEMP>(SN, us, vs, ps, ts, dx2, tab);
+            double ts = 0.0, rps = 0.0;
+            if (TEMP) {
+                rps = rcp(ps);            // shared by the unscaling and by 1/rho of the predicted row
+                ts = (B0.st - dt * t.dst) * (rps * inv_dx2);
+            }
+            make_row_r<TEMP>(SN, us, vs, ps, ts, dx2, tab, rps);
         }
         // ---- tracer, axis-0 flux through the face between rows r-1 and r
         double f0_cur = 0.0;
         if (TRACER && r >= ja) f0_cur = face_flux<TRACER == 2>(BM.v, qmm, qm, q0, qp, a.dtdx);
         // ---- corrector: output row r-1 from predicted rows r-2, r-1, r and base row r-1
         if (r >= ja + 1) {
-            const Tend t = tendencies<TEMP>(SM, S0, SN, inv_dx, h_dx, inv_dx2);
+            const Tend t = tendencies<TEMP>(SM, S0, SN, g_dx, h_dx, mu_dx2);
             const double un = BM.u - dt * t.du;
             const double vn = BM.v - dt * t.dv;
             const double pn = BM.p - dt * t.dp;
             double tn = 0.0, qn = 0.0;
-            if (TEMP) tn = (BM.st - dt * t.dst) * rcp(pn * dx2);
+            if (TEMP) tn = (BM.st - dt * t.dst) * (rcp(pn) * inv_dx2);
             if (TRACER) {
                 const double qs = qm - f0_cur + f0_prev;  // after the axis-0 pass
                 const double qs_w = from_west(qs), qs_e = from_east(qs);
