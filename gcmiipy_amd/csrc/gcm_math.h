@@ -131,19 +131,22 @@ __device__ __forceinline__ double visc_u(double uc, double uw, double ue, double
 }
 
 // density_from + geopotential_from + scaling, matsumo_temp.py:13-19,28-30,45-47.
-// Returns 1/rho, geo = p/(G rho), scaled_t = p t dx dx.
-struct Thermo { double inv_rho, geo, st; };
-__device__ __forceinline__ Thermo thermo(double p, double t, double dx2, const double *tab,
-                                         double rcp_p) {
+// Returns Rd T / p (= Rd / (rho Rd) ... i.e. 1/rho), geo = p/(G rho) and the mass-weighted
+// theta p t.  Two constant factors are folded away: the reference's scaling/unscaling by
+// dx*dx (matsumo_temp.py:28-35) cancels exactly in  t* = (p t dx^2 - dt adv(p t dx^2)) /
+// (p* dx^2)  because adv() is linear, and Rd of 1/rho = Rd T / p is carried by the viscosity
+// constant (mu Rd / dx^2).  Both move results by O(1 ulp).
+struct Thermo { double t_over_p, geo, st; };
+__device__ __forceinline__ Thermo thermo(double p, double t, const double *tab, double rcp_p) {
     double temp = t * exner(p, tab);           // t / (1e5/p)**kappa
     Thermo r;
-    r.inv_rho = kRd * temp * rcp_p;            // 1 / (p / (Rd T))
+    r.t_over_p = temp * rcp_p;                 // 1/rho = Rd * (T / p)
     r.geo = temp * (kRd / kG);                 // p / (G rho) = Rd T / G
-    r.st = p * t * dx2;
+    r.st = p * t;
     return r;
 }
-__device__ __forceinline__ Thermo thermo(double p, double t, double dx2, const double *tab) {
-    return thermo(p, t, dx2, tab, rcp(p));
+__device__ __forceinline__ Thermo thermo(double p, double t, const double *tab) {
+    return thermo(p, t, tab, rcp(p));
 }
 
 // ---- tracer face flux (two_d.py:103-116,135-149; flux_limiter.py:10-27) -----------

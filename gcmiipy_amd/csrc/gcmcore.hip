@@ -316,7 +316,7 @@ static Sw2dArgs base_args(gcm_handle *h, double dt) {
     a.h_dx = 0.5 / h->cfg.dx;
     a.dtdx = dt / h->cfg.dx;
     a.g_dx = 9.8 / h->cfg.dx;
-    a.mu_dx2 = (18.5 * 1e-6) / (h->cfg.dx * h->cfg.dx);
+    a.mu_dx2 = (18.5 * 1e-6) * 287.0 / (h->cfg.dx * h->cfg.dx);   // mu_air Rd / dx^2 (see thermo())
     a.inv_dx2_ = a.inv_dx2;
     return a;
 }

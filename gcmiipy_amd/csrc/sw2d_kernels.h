@@ -13,7 +13,7 @@ constexpr int kStripCols = 60;   // output columns per wave in the fused kernel 
 struct Sw2dArgs {
     const double *bu, *bv, *bp, *bt, *bq;   // base (time n) state
     const double *su, *sv, *sp, *st;        // stage state the tendencies are evaluated on
-    const double *sgeo, *sirho, *sst;       // staged TEMP: derived fields of the stage state
+    const double *sgeo, *sirho, *sst;       // staged TEMP: geo, T/p, p*t of the stage state
     double *ou, *ov, *op, *ot, *oq;         // output
     double *dgeo, *dirho, *dst;             // derive kernel outputs
     const double *exner_tab;                // device copy of the 256-double exner table
@@ -24,7 +24,7 @@ struct Sw2dArgs {
     double dt, dx, inv_dx, dx2, inv_dx2;
     double h_dx;                            // 0.5 / dx (exact halving folded in)
     double dtdx;                            // dt / dx
-    double g_dx, mu_dx2, inv_dx2_;          // G / dx, mu_air / dx^2, 1 / dx^2
+    double g_dx, mu_dx2, inv_dx2_;          // G / dx, mu_air Rd / dx^2, 1 / dx^2
 };
 
 // staged variant

@@ -47,9 +47,9 @@ __global__ __launch_bounds__(256) void sw2d_derive_kernel(Sw2dArgs a) {
     const int j = a.j0 + blockIdx.y * 4 + threadIdx.y;
     if (i >= a.W || j >= a.j1) return;
     const long o = (long)j * a.W + i;
-    Thermo th = thermo(a.sp[o], a.st[o], a.dx2, tab);
+    Thermo th = thermo(a.sp[o], a.st[o], tab);
     a.dgeo[o] = th.geo;
-    a.dirho[o] = th.inv_rho;
+    a.dirho[o] = th.t_over_p;
     a.dst[o] = th.st;
 }
 
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256) void sw2d_stage_kernel(Sw2dArgs a) {
     if (TEMP) {
         const double dst = adv_geo(uc, uw, vc, vn, a.sst[rc + i], a.sst[rc + iw], a.sst[rc + ie],
                                    a.sst[rn + i], a.sst[rs + i], a.h_dx);
-        const double tt = bp * a.bt[o] * a.dx2 - a.dt * dst;
-        a.ot[o] = tt * (rcp(pnew) * a.inv_dx2);  // unscaling, matsumo_temp.py:33-35
+        const double tt = bp * a.bt[o] - a.dt * dst;
+        a.ot[o] = tt * rcp(pnew);  // unscaling, matsumo_temp.py:33-35 (dx*dx cancels)
     }
 }
 
@@ -167,15 +167,15 @@ struct Row {
 
 template <bool TEMP>
 __device__ __forceinline__ void make_row_r(Row &r, double u, double v, double p, double t,
-                                           double dx2, const double *tab, double rcp_p) {
+                                           const double *tab, double rcp_p) {
     r.u = u;
     r.v = v;
     r.p = p;
     if (TEMP) {
-        Thermo th = thermo(p, t, dx2, tab, rcp_p);
+        Thermo th = thermo(p, t, tab, rcp_p);
         r.st = th.st;
         r.g = th.geo;
-        r.irho = th.inv_rho;
+        r.irho = th.t_over_p;
     } else {
         r.st = 0.0;
         r.g = p;
@@ -185,8 +185,8 @@ __device__ __forceinline__ void make_row_r(Row &r, double u, double v, double p,
 
 template <bool TEMP>
 __device__ __forceinline__ void make_row(Row &r, double u, double v, double p, double t,
-                                         double dx2, const double *tab) {
-    make_row_r<TEMP>(r, u, v, p, t, dx2, tab, TEMP ? rcp(p) : 0.0);
+                                         const double *tab) {
+    make_row_r<TEMP>(r, u, v, p, t, tab, TEMP ? rcp(p) : 0.0);
 }
 
 struct Tend {
@@ -252,8 +252,7 @@ struct FusedCtx {
     __device__ __forceinline__ void iter(int r, Row &BM, Row &B0, Row &BP, Row &SN, Row &SM,
                                          Row &S0, Raw &nxt, double &qmm, double &qm, double &q0,
                                          double &qp) {
-        const double dt = a.dt, g_dx = a.g_dx, h_dx = a.h_dx, mu_dx2 = a.mu_dx2, inv_dx2 = a.inv_dx2,
-                     dx2 = a.dx2;
+        const double dt = a.dt, g_dx = a.g_dx, h_dx = a.h_dx, mu_dx2 = a.mu_dx2;
         // ---- predictor: predicted row r from base rows r-1, r, r+1
         {
             const Tend t = tendencies<TEMP>(BM, B0, BP, g_dx, h_dx, mu_dx2);
@@ -263,9 +262,9 @@ struct FusedCtx {
             double ts = 0.0, rps = 0.0;
             if (TEMP) {
                 rps = rcp(ps);            // shared by the unscaling and by 1/rho of the predicted row
-                ts = (B0.st - dt * t.dst) * (rps * inv_dx2);
+                ts = (B0.st - dt * t.dst) * rps;
             }
-            make_row_r<TEMP>(SN, us, vs, ps, ts, dx2, tab, rps);
+            make_row_r<TEMP>(SN, us, vs, ps, ts, tab, rps);
         }
         // ---- tracer, axis-0 flux through the face between rows r-1 and r
         double f0_cur = 0.0;
@@ -277,7 +276,7 @@ struct FusedCtx {
             const double vn = BM.v - dt * t.dv;
             const double pn = BM.p - dt * t.dp;
             double tn = 0.0, qn = 0.0;
-            if (TEMP) tn = (BM.st - dt * t.dst) * (rcp(pn) * inv_dx2);
+            if (TEMP) tn = (BM.st - dt * t.dst) * rcp(pn);
             if (TRACER) {
                 const double qs = qm - f0_cur + f0_prev;  // after the axis-0 pass
                 const double qs_w = from_west(qs), qs_e = from_east(qs);
@@ -296,7 +295,7 @@ struct FusedCtx {
         }
         // ---- slide south: the oldest base slot takes row r+2, prefetch row r+3
         f0_prev = f0_cur;
-        make_row<TEMP>(BM, nxt.u, nxt.v, nxt.p, nxt.t, dx2, tab);
+        make_row<TEMP>(BM, nxt.u, nxt.v, nxt.p, nxt.t, tab);
         if (TRACER) {
             qmm = qm;
             qm = q0;
@@ -338,13 +337,13 @@ __global__ __launch_bounds__(64) void sw2d_fused_kernel(Sw2dArgs a) {
 
     Row A, B, C, X, Y, Z;
     Raw x = c.load(ja - 2);
-    make_row<TEMP>(A, x.u, x.v, x.p, x.t, a.dx2, tab);
+    make_row<TEMP>(A, x.u, x.v, x.p, x.t, tab);
     double qmm = 0.0, qm = x.q;
     x = c.load(ja - 1);
-    make_row<TEMP>(B, x.u, x.v, x.p, x.t, a.dx2, tab);
+    make_row<TEMP>(B, x.u, x.v, x.p, x.t, tab);
     double q0 = x.q;
     x = c.load(ja);
-    make_row<TEMP>(C, x.u, x.v, x.p, x.t, a.dx2, tab);
+    make_row<TEMP>(C, x.u, x.v, x.p, x.t, tab);
     double qp = x.q;
     Raw nxt = c.load(ja + 1);
     X = Y = Z = A;  // overwritten before first use
