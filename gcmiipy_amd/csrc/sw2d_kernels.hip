@@ -162,7 +162,7 @@ void launch_tracer_axis(const Sw2dArgs &a, int axis, bool limit, const double *q
 // One row of a state (base or predicted) as a lane keeps it: own column and, for TEMP,
 // the derived fields.
 struct Row {
-    double u, v, p, st, g, irho;
+    double u, uw, v, vw, p, st, g, irho;   // uw, vw: west neighbours, shifted once per row
 };
 
 template <bool TEMP>
@@ -171,6 +171,8 @@ __device__ __forceinline__ void make_row_r(Row &r, double u, double v, double p,
     r.u = u;
     r.v = v;
     r.p = p;
+    r.uw = from_west(u);
+    r.vw = from_west(v);
     if (TEMP) {
         Thermo th = thermo(p, t, tab, rcp_p);
         r.st = th.st;
@@ -197,10 +199,8 @@ struct Tend {
 template <bool TEMP>
 __device__ __forceinline__ Tend tendencies(const Row &RM, const Row &R0, const Row &RP,
                                            double g_dx, double h_dx, double mu_dx2) {
-    // i-1 / i+1 neighbours by DPP at the point of use (cheaper than carrying them in VGPRs)
     const double ue = from_east(R0.u), ve = from_east(R0.v);
-    const double uw = from_west(R0.u), vw = from_west(R0.v);
-    const double usw = from_west(RP.u), vsw = from_west(RP.v);
+    const double uw = R0.uw, vw = R0.vw, usw = RP.uw, vsw = RP.vw;
     const double pw = from_west(R0.p), pe = from_east(R0.p);
     const double ge = TEMP ? from_east(R0.g) : pe;
     Tend t;
