@@ -15,4 +15,14 @@ built: nothing here computes on the CPU.
 from . import _lib  # noqa: F401  (fails loudly when the HIP library is missing)
 from .core import Core, GcmError, device_count  # noqa: F401
 
-__all__ = ["Core", "GcmError", "device_count"]
+
+
+def clear_cache():
+    """free the device state the per-call drop-ins keep between calls"""
+    from . import matsuno_c_grid, dynamics
+    for cache in (matsuno_c_grid._cache, dynamics._cache):
+        while cache:
+            cache.popitem()[1].close()
+
+
+__all__ = ["Core", "GcmError", "device_count", "clear_cache"]

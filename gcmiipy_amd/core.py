@@ -108,7 +108,7 @@ class Core:
     def _prep_in(self, arrs):
         out = []
         for f, a in enumerate(arrs):
-            out.append(None if a is None else as_f64(a, self.shape_of(f), "pu vtq"[f] if f < 2 else "puvtq"[f]))
+            out.append(None if a is None else as_f64(a, self.shape_of(f), "puvtq"[f]))
         return out
 
     # -- state -------------------------------------------------------------------

@@ -245,3 +245,30 @@ def test_grey_radiation_and_solar_timestep(g):
         t_n, g_n = grey_solar.solar_timestep(t, p, gv, float(d["dt"]), utc, geom)
         assert rel_err(t_n, d["t_n_" + tag]) < TOL
         assert rel_err(g_n.gt, d["gt_n_" + tag]) < TOL
+
+
+def test_full_size_properties_c4(g):
+    """BASELINE configs[3] size (1440x720x24), 3 steps: properties that do not need the oracle --
+    sum(p) is conserved (the continuity equation is in flux form: the zonal term telescopes per
+    row, the meridional one over the closed pole edge), the pole-edge v row is exactly zero
+    (dynamics.py:222), nothing goes non-finite, and bands == single domain."""
+    from gcmiipy_amd import geometry
+    H, W, L = 720, 1440, 24
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    rng = np.random.default_rng(0)
+    p = 1e5 + 10 * rng.standard_normal((H, W))
+    u = rng.standard_normal((L, H, W))
+    v = rng.standard_normal((L, H, W))
+    v[:, -1, :] = 0
+    t = (300 + rng.standard_normal((L, H, W))) * ((1e5 / (p * geom.sig + geom.ptop)) ** (287.0 / 1004.0))
+    q = 3e-6 * (1 + 0.1 * rng.random((L, H, W)))
+    c = g.Core(g._lib.PE25D, W, H, L, geom=geom)
+    c.set_state(p, u, v, t, q)
+    c.step(3, 1.0)
+    assert c.diag(g._lib.DIAG_ANY_NAN) == 0.0
+    pn, un, vn, tn, qn = c.get_state()
+    c.close()
+    assert abs(pn.sum() - p.sum()) < 1e-12 * p.sum()
+    assert np.all(vn[:, -1, :] == 0.0)
+    assert all(np.isfinite(x).all() for x in (pn, un, vn, tn, qn))
+    assert np.max(np.abs(un - u)) > 1e-6                    # it did move
