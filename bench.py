@@ -35,6 +35,9 @@ WORKLOADS = {
     # cells are (k, j, i) points; 4 3-D fields + p: (64 + 16/L) bytes per cell-update
     "c4": ("2.5-D sigma-level primitive equations, 1440x720x24 fp64 (BASELINE configs[3])",
            720, 1440, 24, "PE25D", None, 64.0 + 16.0 / 24, 1.0),
+    # the same workload with arithmetic and storage in fp32 (BASELINE configs[4]: fp32 vs fp64 sweep)
+    "c4_f32": ("2.5-D sigma-level primitive equations, 1440x720x24 fp32",
+               720, 1440, 24, "PE25D", None, 32.0 + 8.0 / 24, 1.0),
 }
 DX = 300e3
 
@@ -44,7 +47,7 @@ def synth(name, H, W, L=1, row0=0, nrows=None, geom=None):
     rng = np.random.default_rng(0)
     nrows = H if nrows is None else nrows
     sl = slice(row0, row0 + nrows)
-    if name == "c4":
+    if name.startswith("c4"):
         p = 1e5 + 10 * rng.standard_normal((H, W))
         u = rng.standard_normal((L, H, W))
         v = rng.standard_normal((L, H, W))
@@ -69,7 +72,7 @@ def cpu_baseline(name):
     """the oracle (NumPy restatement, bit-identical to the reference) on the host, 1 core"""
     from oracle import sw2d, sw2d_temp, tracer
     _, H, W, L, _, _, _, dt = WORKLOADS[name]
-    if name == "c4":
+    if name.startswith("c4"):
         # bounded sample: the same recipe on a 360x180x24 grid (1/16 of the cells), 2 steps
         from oracle import dynamics, geometry as ogeo
         h, w = 180, 360
@@ -135,7 +138,8 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
                       variant=_lib.VARIANT_FUSED if variant == "fused" else _lib.VARIANT_STAGED,
                       filter=not os.environ.get("GCM_BENCH_NOFILTER"),   # diagnostic only
                       nranks=world, rank=rank, global_height=H, row0=row0, device=cx.local,
-                      stream=torch.cuda.current_stream().cuda_stream, halo_steps=k)
+                      stream=torch.cuda.current_stream().cuda_stream, halo_steps=k,
+                      dtype="f32" if name.endswith("_f32") else "f64")
         core.set_state(**synth(name, H, W, L, row0, nrows, geom))
         eng = HipBandEngine(core, torch, stream_aware=cx.backend == "nccl") if world > 1 else None
         runner = BandRunner(eng, rank, world, dist)
@@ -177,6 +181,7 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
         value = cells * steps / el
         res = {"workload": desc, "grid": [W, H] + ([L] if L > 1 else []), "n_gpus": world, "steps": steps,
                "warmup": warmup, "value": value, "ms_per_step": el / steps * 1e3,
+               "dtype": "f32" if name.endswith("_f32") else "f64",
                "bytes_per_cell_update": bpc,
                "hbm_roofline_frac_whole_job": value * bpc / (world * HBM_PEAK_GBS * 1e9),
                "decomposition": "%d latitude band(s)%s" % (
@@ -203,7 +208,7 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
             traffic = None
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
-                traffic = tj[name][("gcm::" + kname.split(" ")[0])]["hbm_bytes_per_launch"]
+                traffic = tj[name][("gcm::" + kname.split(" ")[0])]["hbm_bytes_per_launch"]   # fp64 runs only
             except Exception:
                 pass
             res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -261,7 +266,9 @@ def main():
                 continue
             if cx.world > 1 and name == "c2":
                 continue                                   # 360 rows: not a multi-GPU workload
-            st, wu = {"c2": (600, 50), "c3": (100, 10), "c4": (16, 3)}[name]      # c2: the noise IC goes unstable (in the reference too) near step 1300
+            if cx.world > 1 and name == "c4_f32":
+                continue
+            st, wu = {"c2": (600, 50), "c3": (100, 10), "c4": (16, 3), "c4_f32": (16, 3)}[name]      # c2: the noise IC goes unstable (in the reference too) near step 1300
             r = run_workload(cx, name, st, wu, want_kernel=cx.world == 1)
             if cx.world > 1:                               # same-run single-GPU reference (rank 0 alone)
                 r1 = run_workload(cx, name, max(st // 2, 4), 2, world=1, want_kernel=False)
@@ -276,7 +283,7 @@ def main():
             "metric": "cell-updates/s (C-grid Matsuno step)", "value": main_res["value"],
             "unit": "cell-updates/s", "n_gpus": cx.world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": main_res["dtype"], "data": "synthetic",
             "config": {"workload": main_res["workload"], "grid": main_res["grid"], "variant": a.variant,
                        "decomposition": main_res["decomposition"],
                        "bytes_per_cell_update": main_res["bytes_per_cell_update"]},

@@ -16,6 +16,7 @@ SW2D, SW2D_TEMP, PE2D, PE25D = 1, 2, 3, 4
 P, U, V, T, Q = 0, 1, 2, 3, 4
 TRACER_NONE, TRACER_UPWIND, TRACER_VANLEER = 0, 1, 2
 VARIANT_AUTO, VARIANT_STAGED, VARIANT_FUSED = 0, 1, 2
+F64, F32 = 0, 1
 ADV_UPWIND, ADV_FV_UPWIND, ADV_FV_PLAIN, ADV_VANLEER, ADV_MOMENTUM = range(5)
 DIAG_ANY_NAN, DIAG_MAX_U, DIAG_MEAN_P, DIAG_SUM_P, DIAG_MIN_U, DIAG_MAX_V, DIAG_MIN_V = range(7)
 OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
@@ -29,7 +30,7 @@ class Config(C.Structure):
         ("height", C.c_int32), ("layers", C.c_int32), ("tracer", C.c_int32),
         ("variant", C.c_int32), ("filter", C.c_int32), ("nranks", C.c_int32),
         ("rank", C.c_int32), ("global_height", C.c_int32), ("row0", C.c_int32),
-        ("device", C.c_int32), ("halo_steps", C.c_int32),
+        ("device", C.c_int32), ("dtype", C.c_int32), ("halo_steps", C.c_int32),
         ("dx", C.c_double), ("dy", C.c_double), ("ptop", C.c_double),
         ("dx_j", _dp), ("dx_h", _dp), ("sig", _dp), ("dsig", _dp), ("sigb", _dp),
         ("sigt", _dp), ("heightmap", _dp), ("cor_u", _dp), ("cor_v", _dp), ("stream", C.c_void_p),

@@ -48,7 +48,7 @@ class Core:
 
     def __init__(self, model, width, height, layers=1, dx=0.0, tracer=_lib.TRACER_NONE,
                  variant=_lib.VARIANT_AUTO, geom=None, filter=True, nranks=1, rank=0,
-                 global_height=None, row0=0, device=-1, stream=None, halo_steps=1, coriolis=False):
+                 global_height=None, row0=0, device=-1, stream=None, halo_steps=1, coriolis=False, dtype="f64"):
         self.model, self.W, self.H, self.L = model, int(width), int(height), int(layers)
         self.nranks, self.rank = nranks, rank
         cfg = _lib.Config()
@@ -61,6 +61,8 @@ class Core:
         cfg.row0 = row0
         cfg.device = device
         cfg.halo_steps = halo_steps
+        cfg.dtype = {"f64": _lib.F64, "f32": _lib.F32}[dtype]
+        self.dtype = dtype
         self.halo_steps = halo_steps
         cfg.dx = float(dx)
         cfg.stream = stream

@@ -533,11 +533,12 @@ int gcm_sync(gcm_handle *h) {
 // ------------------------------------------------------------------ diagnostics
 }  // extern "C"
 
-__global__ __launch_bounds__(256) void diag_kernel(const double *x, long n, double *out) {
+template <typename T>
+__global__ __launch_bounds__(256) void diag_kernel(const T *x, long n, double *out) {
     // out[4*b + {0,1,2,3}] = max, min, sum, nan-count of this block's grid-stride share
     double mx = -INFINITY, mn = INFINITY, sm = 0.0, nn = 0.0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const double v = x[i];
+        const double v = (double)x[i];
         if (v != v) nn += 1.0;
         mx = fmax(mx, v);
         mn = fmin(mn, v);
@@ -582,13 +583,19 @@ int gcm_diag(gcm_handle *h, int kind, double *out) {
         case GCM_DIAG_MAX_V: case GCM_DIAG_MIN_V: f = GCM_V; break;
         default: return fail(h, GCM_ERR_ARG, "gcm_diag: unknown kind");
     }
+    int f32 = 0;
+    const void *xv = nullptr;
     if (h->pe) {
-        x = pe25d_field(h->pe, f, &n);
+        xv = pe25d_field(h->pe, f, &n, &f32);
     } else {
         x = h->cur[f];
     }
     const int nb = gcm_handle::kDiagBlocks;
-    hipLaunchKernelGGL(diag_kernel, dim3(nb), dim3(256), 0, h->stream, x, n, h->diag_dev);
+    if (f32)
+        hipLaunchKernelGGL(diag_kernel<float>, dim3(nb), dim3(256), 0, h->stream, (const float *)xv, n, h->diag_dev);
+    else
+        hipLaunchKernelGGL(diag_kernel<double>, dim3(nb), dim3(256), 0, h->stream,
+                           h->pe ? (const double *)xv : x, n, h->diag_dev);
     std::vector<double> part(4 * nb);
     HIPCHK(h, hipMemcpyAsync(part.data(), h->diag_dev, sizeof(double) * 4 * nb,
                              hipMemcpyDeviceToHost, h->stream));

@@ -28,7 +28,7 @@ int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, do
                     const double *lat, const double *lon, double *dTdt_host, double *dtg_host,
                     hipStream_t s, std::string *err);
 int pe25d_energy(Pe25d *m, const double *area_host, int area_len, double out[4], std::string *err);
-const double *pe25d_field(Pe25d *m, int field, long *n);
+const void *pe25d_field(Pe25d *m, int field, long *n, int *f32);
 void pe25d_timing(Pe25d *m, std::vector<hipEvent_t> *ev, size_t *used);
 
 }  // namespace gcm

@@ -32,28 +32,40 @@ struct FftPlan {
     int inplace;                   // 1: only radices 2,3,4,5 and N/2 <= kMaxBfly*256: single-buffer passes
 };
 
-struct PeArgs {
+template <typename T> struct Vec2;
+template <> struct Vec2<double> { using type = double2; };
+template <> struct Vec2<float> { using type = float2; };
+template <typename V> using Sc = decltype(V().x);                    // scalar type of a 2-vector
+template <typename V> __device__ __forceinline__ V mkv(Sc<V> a, Sc<V> b) { V r; r.x = a; r.y = b; return r; }
+
+// real-type specific pieces: reciprocal and (p/P0)**kappa (fp32: v_rcp_f32 is 1 ulp; powf)
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float exner(float p, const double *) { return __powf(p * 1e-5f, (float)kKappa); }
+
+template <typename T>
+struct PeArgsT {
+    using T2 = typename Vec2<T>::type;
     // base (time n) and stage state, device layout, pointers at interior row 0
-    const double *p, *u, *v, *t, *q;
-    const double *sp, *su, *sv, *st, *sq;
-    double *op, *ou, *ov, *ot, *oq;
+    const T *p, *u, *v, *t, *q;
+    const T *sp, *su, *sv, *st, *sq;
+    T *op, *ou, *ov, *ot, *oq;
     // intermediates
-    double *spu, *phi, *rho, *pgfu;        // 3-D
-    double *pit, *pn;                      // 2-D
+    T *spu, *phi, *rho, *pgfu;        // 3-D
+    T *pit, *pn;                      // 2-D
     // tables (device)
-    const double *inv_dxj, *inv_dxh;       // [Hg] reciprocals of geometry.py:136-137
-    const double *sig, *dsig, *inv_dsig, *sigb, *sigt;  // [L]
-    const double *heightmap;               // [Hg][W] (global rows) or null
-    const double *cor_u, *cor_v;           // [Hg] Coriolis factors or null (dynamics.py:82-92)
-    const double *smul;                    // [Hg][W/2+1] filter multiplier (low_pass.py:61-72)
-    const double2 *tw;                     // [W] exp(-2 pi i n / W)
-    const double *exner_tab;
+    const T *inv_dxj, *inv_dxh;       // [Hg] reciprocals of geometry.py:136-137
+    const T *sig, *dsig, *inv_dsig, *sigb, *sigt;  // [L]
+    const T *heightmap;               // [Hg][W] (global rows) or null
+    const T *cor_u, *cor_v;           // [Hg] Coriolis factors or null (dynamics.py:82-92)
+    const T *smul;                    // [Hg][W/2+1] filter multiplier (low_pass.py:61-72)
+    const T2 *tw;                     // [W] exp(-2 pi i n / W)
+    const double *exner_tab;               // always float64 (gcm_math.h exner())
     FftPlan plan;
     int W, H, L, Hg, row0;                 // local rows, global rows, first global row
     int wrap;                              // 1: rows wrap modulo H (single band)
     int filter;
     int j0, j1;                            // rows to produce
-    double dt, inv_dy, ptop;
+    T dt, inv_dy, ptop;
 };
 
 __device__ __forceinline__ int wrapi(int x, int n) {
@@ -70,26 +82,30 @@ struct Idx {
 
 // ---------------------------------------------------------------- FFT in LDS
 // Stockham autosort, mixed radix.  x -> result returned in x or y (pointer returned).
-__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
-    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+template <typename V>
+__device__ __forceinline__ V cmul(V a, V b) {
+    return mkv<V>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+template <typename V>
+__device__ __forceinline__ V cadd(V a, V b) { return mkv<V>(a.x + b.x, a.y + b.y); }
+template <typename V>
+__device__ __forceinline__ V csub(V a, V b) { return mkv<V>(a.x - b.x, a.y - b.y); }
 // -i z (forward transforms) or +i z (inverse)
-template <bool INV>
-__device__ __forceinline__ double2 rot(double2 z) {
-    return INV ? make_double2(-z.y, z.x) : make_double2(z.y, -z.x);
+template <bool INV, typename V>
+__device__ __forceinline__ V rot(V z) {
+    return INV ? mkv<V>(-z.y, z.x) : mkv<V>(z.y, -z.x);
 }
-template <bool INV>
-__device__ __forceinline__ double2 twid(const double2 *tw, int idx) {
-    double2 w = tw[idx];
+template <bool INV, typename V>
+__device__ __forceinline__ V twid(const V *tw, int idx) {
+    V w = tw[idx];
     if (INV) w.y = -w.y;
     return w;
 }
 
-template <bool INV>
-__device__ double2 *fft_lds(double2 *x, double2 *y, const double2 *tw, const FftPlan &P) {
+template <bool INV, typename V>
+__device__ V *fft_lds(V *x, V *y, const V *tw, const FftPlan &P) {
+    using T = Sc<V>;
     const int N = P.n;
     int Ns = 1;
     for (int pass = 0; pass < P.nrad; ++pass) {
@@ -103,45 +119,45 @@ __device__ double2 *fft_lds(double2 *x, double2 *y, const double2 *tw, const Fft
             const int j0 = blk * Ns * r + k;
             const int t1 = k * tstep;
             if (r == 2) {
-                const double2 a0 = x[b], a1 = cmul(x[b + nb], twid<INV>(tw, t1));
+                const V a0 = x[b], a1 = cmul(x[b + nb], twid<INV>(tw, t1));
                 y[j0] = cadd(a0, a1);
                 y[j0 + Ns] = csub(a0, a1);
             } else if (r == 4) {
-                const double2 a0 = x[b];
-                const double2 a1 = cmul(x[b + nb], twid<INV>(tw, t1));
-                const double2 a2 = cmul(x[b + 2 * nb], twid<INV>(tw, 2 * t1));
-                const double2 a3 = cmul(x[b + 3 * nb], twid<INV>(tw, 3 * t1));
-                const double2 s02 = cadd(a0, a2), d02 = csub(a0, a2);
-                const double2 s13 = cadd(a1, a3), jd = rot<INV>(csub(a1, a3));
+                const V a0 = x[b];
+                const V a1 = cmul(x[b + nb], twid<INV>(tw, t1));
+                const V a2 = cmul(x[b + 2 * nb], twid<INV>(tw, 2 * t1));
+                const V a3 = cmul(x[b + 3 * nb], twid<INV>(tw, 3 * t1));
+                const V s02 = cadd(a0, a2), d02 = csub(a0, a2);
+                const V s13 = cadd(a1, a3), jd = rot<INV>(csub(a1, a3));
                 y[j0] = cadd(s02, s13);
                 y[j0 + Ns] = cadd(d02, jd);
                 y[j0 + 2 * Ns] = csub(s02, s13);
                 y[j0 + 3 * Ns] = csub(d02, jd);
             } else if (r == 3) {
-                const double2 a0 = x[b];
-                const double2 a1 = cmul(x[b + nb], twid<INV>(tw, t1));
-                const double2 a2 = cmul(x[b + 2 * nb], twid<INV>(tw, 2 * t1));
-                const double2 t = cadd(a1, a2);
-                const double2 m = make_double2(a0.x - 0.5 * t.x, a0.y - 0.5 * t.y);
-                double2 sv = rot<INV>(csub(a1, a2));
-                sv.x *= 0.86602540378443864676;  // sin(2 pi / 3)
-                sv.y *= 0.86602540378443864676;
+                const V a0 = x[b];
+                const V a1 = cmul(x[b + nb], twid<INV>(tw, t1));
+                const V a2 = cmul(x[b + 2 * nb], twid<INV>(tw, 2 * t1));
+                const V t = cadd(a1, a2);
+                const V m = mkv<V>(a0.x - T(0.5) * t.x, a0.y - T(0.5) * t.y);
+                V sv = rot<INV>(csub(a1, a2));
+                sv.x *= T(0.86602540378443864676);  // sin(2 pi / 3)
+                sv.y *= T(0.86602540378443864676);
                 y[j0] = cadd(a0, t);
                 y[j0 + Ns] = cadd(m, sv);
                 y[j0 + 2 * Ns] = csub(m, sv);
             } else if (r == 5) {
-                constexpr double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
-                constexpr double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
-                const double2 a0 = x[b];
-                const double2 a1 = cmul(x[b + nb], twid<INV>(tw, t1));
-                const double2 a2 = cmul(x[b + 2 * nb], twid<INV>(tw, 2 * t1));
-                const double2 a3 = cmul(x[b + 3 * nb], twid<INV>(tw, 3 * t1));
-                const double2 a4 = cmul(x[b + 4 * nb], twid<INV>(tw, 4 * t1));
-                const double2 p1 = cadd(a1, a4), p2 = cadd(a2, a3), q1 = csub(a1, a4), q2 = csub(a2, a3);
-                const double2 m1 = make_double2(a0.x + c1 * p1.x + c2 * p2.x, a0.y + c1 * p1.y + c2 * p2.y);
-                const double2 m2 = make_double2(a0.x + c2 * p1.x + c1 * p2.x, a0.y + c2 * p1.y + c1 * p2.y);
-                const double2 n1 = rot<INV>(make_double2(s1 * q1.x + s2 * q2.x, s1 * q1.y + s2 * q2.y));
-                const double2 n2 = rot<INV>(make_double2(s2 * q1.x - s1 * q2.x, s2 * q1.y - s1 * q2.y));
+                constexpr T c1 = T(0.30901699437494742410), c2 = -T(0.80901699437494742410);
+                constexpr T s1 = T(0.95105651629515357212), s2 = T(0.58778525229247312917);
+                const V a0 = x[b];
+                const V a1 = cmul(x[b + nb], twid<INV>(tw, t1));
+                const V a2 = cmul(x[b + 2 * nb], twid<INV>(tw, 2 * t1));
+                const V a3 = cmul(x[b + 3 * nb], twid<INV>(tw, 3 * t1));
+                const V a4 = cmul(x[b + 4 * nb], twid<INV>(tw, 4 * t1));
+                const V p1 = cadd(a1, a4), p2 = cadd(a2, a3), q1 = csub(a1, a4), q2 = csub(a2, a3);
+                const V m1 = mkv<V>(a0.x + c1 * p1.x + c2 * p2.x, a0.y + c1 * p1.y + c2 * p2.y);
+                const V m2 = mkv<V>(a0.x + c2 * p1.x + c1 * p2.x, a0.y + c2 * p1.y + c1 * p2.y);
+                const V n1 = rot<INV>(mkv<V>(s1 * q1.x + s2 * q2.x, s1 * q1.y + s2 * q2.y));
+                const V n2 = rot<INV>(mkv<V>(s2 * q1.x - s1 * q2.x, s2 * q1.y - s1 * q2.y));
                 y[j0] = cadd(a0, cadd(p1, p2));
                 y[j0 + Ns] = cadd(m1, n1);
                 y[j0 + 2 * Ns] = cadd(m2, n2);
@@ -151,9 +167,9 @@ __device__ double2 *fft_lds(double2 *x, double2 *y, const double2 *tw, const Fft
                 // generic radix: out[q] = sum_m (x_m w^(m k)) W_r^(q m), W_r^t = tw[(t mod r) N/r]
                 const int rstep = N / r;
                 for (int qq = 0; qq < r; ++qq) {
-                    double2 acc = make_double2(0.0, 0.0);
+                    V acc = mkv<V>(T(0.0), T(0.0));
                     for (int m = 0; m < r; ++m) {
-                        const double2 t = cmul(x[b + m * nb], twid<INV>(tw, (m * t1 + ((qq * m) % r) * rstep) % N));
+                        const V t = cmul(x[b + m * nb], twid<INV>(tw, (m * t1 + ((qq * m) % r) * rstep) % N));
                         acc.x += t.x;
                         acc.y += t.y;
                     }
@@ -162,7 +178,7 @@ __device__ double2 *fft_lds(double2 *x, double2 *y, const double2 *tw, const Fft
             }
         }
         __syncthreads();
-        double2 *tmp = x;
+        V *tmp = x;
         x = y;
         y = tmp;
         Ns *= r;
@@ -176,37 +192,38 @@ __device__ double2 *fft_lds(double2 *x, double2 *y, const double2 *tw, const Fft
 constexpr int kFftThreads = 512;
 constexpr int kMaxBfly = 2;    // ceil((N / 2) / kFftThreads) for N <= 1536
 
-template <int R, bool INV>
-__device__ __forceinline__ void butterfly(double2 (&v)[R]) {
+template <int R, bool INV, typename V>
+__device__ __forceinline__ void butterfly(V (&v)[R]) {
+    using T = Sc<V>;
     if (R == 2) {
-        const double2 a0 = v[0], a1 = v[1];
+        const V a0 = v[0], a1 = v[1];
         v[0] = cadd(a0, a1);
         v[1] = csub(a0, a1);
     } else if (R == 4) {
-        const double2 s02 = cadd(v[0], v[2]), d02 = csub(v[0], v[2]);
-        const double2 s13 = cadd(v[1], v[3]), jd = rot<INV>(csub(v[1], v[3]));
+        const V s02 = cadd(v[0], v[2]), d02 = csub(v[0], v[2]);
+        const V s13 = cadd(v[1], v[3]), jd = rot<INV>(csub(v[1], v[3]));
         v[0] = cadd(s02, s13);
         v[1] = cadd(d02, jd);
         v[2] = csub(s02, s13);
         v[3] = csub(d02, jd);
     } else if (R == 3) {
-        const double2 t = cadd(v[1], v[2]);
-        const double2 m = make_double2(v[0].x - 0.5 * t.x, v[0].y - 0.5 * t.y);
-        double2 sv = rot<INV>(csub(v[1], v[2]));
-        sv.x *= 0.86602540378443864676;
-        sv.y *= 0.86602540378443864676;
+        const V t = cadd(v[1], v[2]);
+        const V m = mkv<V>(v[0].x - T(0.5) * t.x, v[0].y - T(0.5) * t.y);
+        V sv = rot<INV>(csub(v[1], v[2]));
+        sv.x *= T(0.86602540378443864676);
+        sv.y *= T(0.86602540378443864676);
         v[0] = cadd(v[0], t);
         v[1] = cadd(m, sv);
         v[2] = csub(m, sv);
     } else {   // R == 5
-        constexpr double c1 = 0.30901699437494742410, c2 = -0.80901699437494742410;
-        constexpr double s1 = 0.95105651629515357212, s2 = 0.58778525229247312917;
-        const double2 a0 = v[0];
-        const double2 p1 = cadd(v[1], v[4]), p2 = cadd(v[2], v[3]), q1 = csub(v[1], v[4]), q2 = csub(v[2], v[3]);
-        const double2 m1 = make_double2(a0.x + c1 * p1.x + c2 * p2.x, a0.y + c1 * p1.y + c2 * p2.y);
-        const double2 m2 = make_double2(a0.x + c2 * p1.x + c1 * p2.x, a0.y + c2 * p1.y + c1 * p2.y);
-        const double2 n1 = rot<INV>(make_double2(s1 * q1.x + s2 * q2.x, s1 * q1.y + s2 * q2.y));
-        const double2 n2 = rot<INV>(make_double2(s2 * q1.x - s1 * q2.x, s2 * q1.y - s1 * q2.y));
+        constexpr T c1 = T(0.30901699437494742410), c2 = -T(0.80901699437494742410);
+        constexpr T s1 = T(0.95105651629515357212), s2 = T(0.58778525229247312917);
+        const V a0 = v[0];
+        const V p1 = cadd(v[1], v[4]), p2 = cadd(v[2], v[3]), q1 = csub(v[1], v[4]), q2 = csub(v[2], v[3]);
+        const V m1 = mkv<V>(a0.x + c1 * p1.x + c2 * p2.x, a0.y + c1 * p1.y + c2 * p2.y);
+        const V m2 = mkv<V>(a0.x + c2 * p1.x + c1 * p2.x, a0.y + c2 * p1.y + c1 * p2.y);
+        const V n1 = rot<INV>(mkv<V>(s1 * q1.x + s2 * q2.x, s1 * q1.y + s2 * q2.y));
+        const V n2 = rot<INV>(mkv<V>(s2 * q1.x - s1 * q2.x, s2 * q1.y - s1 * q2.y));
         v[0] = cadd(a0, cadd(p1, p2));
         v[1] = cadd(m1, n1);
         v[2] = cadd(m2, n2);
@@ -215,11 +232,11 @@ __device__ __forceinline__ void butterfly(double2 (&v)[R]) {
     }
 }
 
-template <int R, bool INV>
-__device__ __forceinline__ void pass_inplace(double2 *x, const double2 *tw, int N, int Ns, unsigned magic) {
+template <int R, bool INV, typename V>
+__device__ __forceinline__ void pass_inplace(V *x, const V *tw, int N, int Ns, unsigned magic) {
     const int nb = N / R;
     const int tstep = N / (Ns * R);
-    double2 v[kMaxBfly][R];
+    V v[kMaxBfly][R];
     int j0[kMaxBfly];
 #pragma unroll
     for (int n = 0; n < kMaxBfly; ++n) {
@@ -247,8 +264,8 @@ __device__ __forceinline__ void pass_inplace(double2 *x, const double2 *tw, int 
     __syncthreads();
 }
 
-template <bool INV>
-__device__ void fft_inplace(double2 *x, const double2 *tw, const FftPlan &P) {
+template <bool INV, typename V>
+__device__ void fft_inplace(V *x, const V *tw, const FftPlan &P) {
     int Ns = 1;
     for (int pass = 0; pass < P.nrad; ++pass) {
         const int r = P.rad[pass];
@@ -262,18 +279,20 @@ __device__ void fft_inplace(double2 *x, const double2 *tw, const FftPlan &P) {
 }
 
 // in-place filter of the two rows packed in x[0..N); result left in x, scaled by 1/N
-__device__ void filter_rows_inplace(double2 *x, const PeArgs &a, int jglob) {
+template <typename T>
+__device__ void filter_rows_inplace(typename Vec2<T>::type *x, const PeArgsT<T> &a, int jglob) {
+    using T2 = typename Vec2<T>::type;
     const int N = a.W;
     fft_inplace<false>(x, a.tw, a.plan);
-    const double *S = a.smul + (long)jglob * (N / 2 + 1);
+    const T *S = a.smul + (long)jglob * (N / 2 + 1);
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        const double s = S[n <= N / 2 ? n : N - n];
+        const T s = S[n <= N / 2 ? n : N - n];
         x[n].x *= s;
         x[n].y *= s;
     }
     __syncthreads();
     fft_inplace<true>(x, a.tw, a.plan);
-    const double inv_n = 1.0 / (double)N;
+    const T inv_n = T(1.0) / (T)N;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         x[n].x *= inv_n;
         x[n].y *= inv_n;
@@ -283,19 +302,21 @@ __device__ void filter_rows_inplace(double2 *x, const PeArgs &a, int jglob) {
 
 // filter two real rows held as re/im of x[0..N): FFT, multiply by S[n] (n folded), inverse FFT.
 // Returns the buffer holding the result (already scaled by 1/N).
-__device__ double2 *filter_rows(double2 *x, double2 *y, const PeArgs &a, int jglob) {
+template <typename T>
+__device__ typename Vec2<T>::type *filter_rows(typename Vec2<T>::type *x, typename Vec2<T>::type *y, const PeArgsT<T> &a, int jglob) {
+    using T2 = typename Vec2<T>::type;
     const int N = a.W;
-    double2 *z = fft_lds<false>(x, y, a.tw, a.plan);
-    const double *S = a.smul + (long)jglob * (N / 2 + 1);
+    T2 *z = fft_lds<false>(x, y, a.tw, a.plan);
+    const T *S = a.smul + (long)jglob * (N / 2 + 1);
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        const double s = S[n <= N / 2 ? n : N - n];
+        const T s = S[n <= N / 2 ? n : N - n];
         z[n].x *= s;
         z[n].y *= s;
     }
     __syncthreads();
-    double2 *o = (z == x) ? y : x;
-    double2 *res = fft_lds<true>(z, o, a.tw, a.plan);
-    const double inv_n = 1.0 / (double)N;
+    T2 *o = (z == x) ? y : x;
+    T2 *res = fft_lds<true>(z, o, a.tw, a.plan);
+    const T inv_n = T(1.0) / (T)N;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         res[n].x *= inv_n;
         res[n].y *= inv_n;
@@ -305,29 +326,31 @@ __device__ double2 *filter_rows(double2 *x, double2 *y, const PeArgs &a, int jgl
 }
 
 // ---------------------------------------------------------------- K1: spu = filter(su * iph(sp))
-__global__ __launch_bounds__(kFftThreads) void pe_spu_filter_kernel(PeArgs a) {
-    extern __shared__ double2 lds[];
-    double2 *x = lds, *y = lds + a.W;
+template <typename T>
+__global__ __launch_bounds__(kFftThreads) void pe_spu_filter_kernel(PeArgsT<T> a) {
+    using T2 = typename Vec2<T>::type;
+    extern __shared__ unsigned char lds_raw[];
+    T2 *x = (T2 *)lds_raw, *y = x + a.W;
     const Idx ix{a.W, a.H, a.L, a.wrap};
     const int j = a.j0 + blockIdx.x;
     const int k0 = 2 * blockIdx.y, k1 = k0 + 1;
     const bool two = k1 < a.L;
     const int W = a.W;
-    const double *sp = a.sp + ix.r2(j);
-    const double *su0 = a.su + ix.r3(j) + (long)k0 * W;
-    const double *su1 = su0 + W;
+    const T *sp = a.sp + ix.r2(j);
+    const T *su0 = a.su + ix.r3(j) + (long)k0 * W;
+    const T *su1 = su0 + W;
     for (int i = threadIdx.x; i < W; i += blockDim.x) {
         const int ie = i + 1 == W ? 0 : i + 1;
-        const double pe = (sp[i] + sp[ie]) * 0.5;      // iph(p), dynamics.py:15-17
-        x[i] = make_double2(su0[i] * pe, two ? su1[i] * pe : 0.0);
+        const T pe = (sp[i] + sp[ie]) * T(0.5);      // iph(p), dynamics.py:15-17
+        x[i] = mkv<typename Vec2<T>::type>(su0[i] * pe, two ? su1[i] * pe : T(0.0));
     }
     __syncthreads();
-    double2 *res = x;
+    T2 *res = x;
     if (a.filter && W > 1) {
         if (a.plan.inplace) filter_rows_inplace(x, a, wrapi(a.row0 + j, a.Hg));
         else res = filter_rows(x, y, a, wrapi(a.row0 + j, a.Hg));
     }
-    double *o0 = a.spu + ix.r3(j) + (long)k0 * W;
+    T *o0 = a.spu + ix.r3(j) + (long)k0 * W;
     for (int i = threadIdx.x; i < W; i += blockDim.x) {
         o0[i] = res[i].x;
         if (two) o0[W + i] = res[i].y;
@@ -338,9 +361,11 @@ __global__ __launch_bounds__(kFftThreads) void pe_spu_filter_kernel(PeArgs a) {
 // The per-level values that the two scans need twice (conv for the reverse cumulative sum,
 // stp for phi) are parked in LDS, park[k][thread], instead of a round trip through HBM.
 constexpr int kColThreads = 128;
-__global__ __launch_bounds__(kColThreads) void pe_column_kernel(PeArgs a) {
+template <typename T>
+__global__ __launch_bounds__(kColThreads) void pe_column_kernel(PeArgsT<T> a) {
     __shared__ double tab[kExnerTabDoubles];
-    extern __shared__ double park[];                 // [L][kColThreads]
+    extern __shared__ unsigned char park_raw[];
+    T *park = (T *)park_raw;                    // [L][kColThreads]
     for (int n = threadIdx.x; n < kExnerTabDoubles; n += kColThreads) tab[n] = a.exner_tab[n];
     __syncthreads();
     const Idx ix{a.W, a.H, a.L, a.wrap};
@@ -354,34 +379,34 @@ __global__ __launch_bounds__(kColThreads) void pe_column_kernel(PeArgs a) {
     const int i = (tile - jrel * iblocks) * kColThreads + threadIdx.x;
     const int j = a.j0 + jrel;
     if (i >= W) return;
-    double *pk = park + threadIdx.x;
+    T *pk = park + threadIdx.x;
     const int iw = i == 0 ? W - 1 : i - 1;
     const int jg = wrapi(a.row0 + j, a.Hg);
-    const double inv_dxj = a.inv_dxj[jg], inv_dy = a.inv_dy;
-    const double spc = a.sp[ix.r2(j) + i], spn = a.sp[ix.r2(j - 1) + i], sps = a.sp[ix.r2(j + 1) + i];
-    const double jph_c = (spc + sps) * 0.5, jph_n = (spn + spc) * 0.5;  // jph(sp) at j, j-1
+    const T inv_dxj = a.inv_dxj[jg], inv_dy = a.inv_dy;
+    const T spc = a.sp[ix.r2(j) + i], spn = a.sp[ix.r2(j - 1) + i], sps = a.sp[ix.r2(j + 1) + i];
+    const T jph_c = (spc + sps) * T(0.5), jph_n = (spn + spc) * T(0.5);  // jph(sp) at j, j-1
     const long c3 = ix.r3(j), n3 = ix.r3(j - 1);
     // ---- aflux, dynamics.py:35-46: pit = sum_k conv (ascending, as np.sum over the outer axis).
     // sigma-dot itself is not materialised: the update kernel rebuilds it on the fly from pit.
-    double pit = 0.0;
+    T pit = T(0.0);
     for (int k = 0; k < L; ++k) {
         const long o = c3 + (long)k * W;
-        const double spv_c = a.sv[o + i] * jph_c;
-        const double spv_n = a.sv[n3 + (long)k * W + i] * jph_n;
+        const T spv_c = a.sv[o + i] * jph_c;
+        const T spv_n = a.sv[n3 + (long)k * W + i] * jph_n;
         pit += ((a.spu[o + i] - a.spu[o + iw]) * inv_dxj + (spv_c - spv_n) * inv_dy) * a.dsig[k];
     }
     a.pit[ix.r2(j) + i] = pit;
     a.pn[ix.r2(j) + i] = a.p[ix.r2(j) + i] - pit * a.dt;   // p_n = p - pit dt, dynamics.py:194
     // ---- compute_geopotential, dynamics.py:111-143
-    const double hmG = a.heightmap ? a.heightmap[(long)jg * W + i] * kG : 0.0 * kG;
-    double t_k = a.st[c3 + i];
-    double ex_k = exner(spc * a.sig[0] + a.ptop, tab);
-    const double t0 = t_k, ex0 = ex_k;                       // level 0, for the k wrap at the top
-    double acc = 0.0;
+    const T hmG = a.heightmap ? a.heightmap[(long)jg * W + i] * T(kG) : T(0.0) * T(kG);
+    T t_k = a.st[c3 + i];
+    T ex_k = exner(spc * a.sig[0] + a.ptop, tab);
+    const T t0 = t_k, ex0 = ex_k;                       // level 0, for the k wrap at the top
+    T acc = T(0.0);
     for (int k = 0; k < L; ++k) {
         const long o = c3 + (long)k * W + i;
-        const double tp = spc * a.sig[k] + a.ptop;
-        double t_n, ex_n;
+        const T tp = spc * a.sig[k] + a.ptop;
+        T t_n, ex_n;
         if (k + 1 < L) {
             t_n = a.st[o + W];
             ex_n = exner(spc * a.sig[k + 1] + a.ptop, tab);
@@ -389,18 +414,18 @@ __global__ __launch_bounds__(kColThreads) void pe_column_kernel(PeArgs a) {
             t_n = t0;            // kp() wraps to the bottom layer, coordinates_3d.py:55-56
             ex_n = ex0;
         }
-        const double tt = t_k * ex_k;                        // t / (P0/tp)**kappa
-        const double rho = tp * rcp(kRd * tt);
+        const T tt = t_k * ex_k;                        // t / (P0/tp)**kappa
+        const T rho = tp * rcp(T(kRd) * tt);
         a.rho[o] = rho;
-        const double s1 = (a.sig[k] * spc * rcp(rho)) * a.dsig[k];
-        const double stp = kCp * ((t_k + t_n) * 0.5) * (ex_k - ex_n);
-        const double s2 = a.sigt[k] * stp;
+        const T s1 = (a.sig[k] * spc * rcp(rho)) * a.dsig[k];
+        const T stp = T(kCp) * ((t_k + t_n) * T(0.5)) * (ex_k - ex_n);
+        const T s2 = a.sigt[k] * stp;
         acc += s1 - s2;
         pk[k * kColThreads] = stp;
         t_k = t_n;
         ex_k = ex_n;
     }
-    double run = acc + hmG;                                  // stp_n[0], dynamics.py:132
+    T run = acc + hmG;                                  // stp_n[0], dynamics.py:132
     a.phi[c3 + i] = run;
     for (int k = 1; k < L; ++k) {                            // phi = cumsum(stp_n), stp_n = km(stp)
         run += pk[(k - 1) * kColThreads];
@@ -409,43 +434,45 @@ __global__ __launch_bounds__(kColThreads) void pe_column_kernel(PeArgs a) {
 }
 
 // ---------------------------------------------------------------- K3: pgfu = filter(pgu + phiu)
-__global__ __launch_bounds__(kFftThreads) void pe_pgf_filter_kernel(PeArgs a) {
-    extern __shared__ double2 lds[];
-    double2 *x = lds, *y = lds + a.W;
+template <typename T>
+__global__ __launch_bounds__(kFftThreads) void pe_pgf_filter_kernel(PeArgsT<T> a) {
+    using T2 = typename Vec2<T>::type;
+    extern __shared__ unsigned char lds_raw[];
+    T2 *x = (T2 *)lds_raw, *y = x + a.W;
     const Idx ix{a.W, a.H, a.L, a.wrap};
     const int j = a.j0 + blockIdx.x;
     const int k0 = 2 * blockIdx.y, k1 = k0 + 1;
     const bool two = k1 < a.L;
     const int W = a.W;
     const int jg = wrapi(a.row0 + j, a.Hg);
-    const double inv_dxj = a.inv_dxj[jg];
-    const double *sp = a.sp + ix.r2(j);
+    const T inv_dxj = a.inv_dxj[jg];
+    const T *sp = a.sp + ix.r2(j);
     const long o0 = ix.r3(j) + (long)k0 * W, o1 = o0 + W;
-    const double sg0 = a.sig[k0], sg1 = two ? a.sig[k1] : 0.0;
+    const T sg0 = a.sig[k0], sg1 = two ? a.sig[k1] : T(0.0);
     for (int i = threadIdx.x; i < W; i += blockDim.x) {
         const int ie = i + 1 == W ? 0 : i + 1;
-        const double pc = sp[i], pe = sp[ie];
-        const double iphp = (pc + pe) * 0.5;
-        const double gradp = (pe - pc) * inv_dxj;
-        double v[2] = {0.0, 0.0};
+        const T pc = sp[i], pe = sp[ie];
+        const T iphp = (pc + pe) * T(0.5);
+        const T gradp = (pe - pc) * inv_dxj;
+        T v[2] = {T(0.0), T(0.0)};
         for (int s = 0; s < (two ? 2 : 1); ++s) {
             const long o = s ? o1 : o0;
-            const double sg = s ? sg1 : sg0;
-            const double phiu = iphp * ((a.phi[o + ie] - a.phi[o + i]) * inv_dxj);      // dynamics.py:159
-            const double ppih = (sg * pc + sg * pe) * 0.5;
-            const double rhou = (a.rho[o + i] + a.rho[o + ie]) * 0.5;
-            const double pgu = ppih * rcp(rhou) * gradp;                                 // dynamics.py:162-165
+            const T sg = s ? sg1 : sg0;
+            const T phiu = iphp * ((a.phi[o + ie] - a.phi[o + i]) * inv_dxj);      // dynamics.py:159
+            const T ppih = (sg * pc + sg * pe) * T(0.5);
+            const T rhou = (a.rho[o + i] + a.rho[o + ie]) * T(0.5);
+            const T pgu = ppih * rcp(rhou) * gradp;                                 // dynamics.py:162-165
             v[s] = pgu + phiu;
         }
-        x[i] = make_double2(v[0], v[1]);
+        x[i] = mkv<typename Vec2<T>::type>(v[0], v[1]);
     }
     __syncthreads();
-    double2 *res = x;
+    T2 *res = x;
     if (a.filter && W > 1) {
         if (a.plan.inplace) filter_rows_inplace(x, a, jg);
         else res = filter_rows(x, y, a, jg);
     }
-    double *out = a.pgfu + o0;
+    T *out = a.pgfu + o0;
     for (int i = threadIdx.x; i < W; i += blockDim.x) {
         out[i] = res[i].x;
         if (two) out[W + i] = res[i].y;
@@ -458,7 +485,8 @@ __global__ __launch_bounds__(kFftThreads) void pe_pgf_filter_kernel(PeArgs a) {
 // are loaded per level.  Tiles (row, 256-column block) are dealt to the 8 XCDs in contiguous
 // runs of rows (as sw2d_fused_kernel does): the blocks resident on one XCD work on adjacent
 // rows at about the same level, so the j+-1 re-reads hit that XCD's L2.
-__global__ __launch_bounds__(256) void pe_update_kernel(PeArgs a) {
+template <typename T>
+__global__ __launch_bounds__(256) void pe_update_kernel(PeArgsT<T> a) {
     const Idx ix{a.W, a.H, a.L, a.wrap};
     const int W = a.W, L = a.L;
     const int iblocks = (W + 255) / 256;
@@ -471,24 +499,24 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgs a) {
     if (i >= W) return;
     const int iw = i == 0 ? W - 1 : i - 1, ie = i + 1 == W ? 0 : i + 1;
     const int jg = wrapi(a.row0 + j, a.Hg);
-    const double inv_dxj = a.inv_dxj[jg], inv_dxh = a.inv_dxh[jg], inv_dy = a.inv_dy, dt = a.dt;
+    const T inv_dxj = a.inv_dxj[jg], inv_dxh = a.inv_dxh[jg], inv_dy = a.inv_dy, dt = a.dt;
     const long rc = ix.r3(j), rn = ix.r3(j - 1), rs = ix.r3(j + 1);
     // surface pressure of the stage state on rows j-1 .. j+2 (level independent)
-    const double *spr = a.sp;
+    const T *spr = a.sp;
     const long p_n = ix.r2(j - 1), p_c = ix.r2(j), p_s = ix.r2(j + 1), p_ss = ix.r2(j + 2);
-    const double sp_c = spr[p_c + i], sp_e = spr[p_c + ie];
-    const double sp_s = spr[p_s + i], sp_se = spr[p_s + ie], sp_ss = spr[p_ss + i];
-    const double sp_n = spr[p_n + i], sp_ne = spr[p_n + ie];
-    const double jph_c = (sp_c + sp_s) * 0.5, jph_ce = (sp_e + sp_se) * 0.5;     // jph(sp) at (j,i),(j,i+1)
-    const double jph_n = (sp_n + sp_c) * 0.5, jph_ne = (sp_ne + sp_e) * 0.5;     // at (j-1,i),(j-1,i+1)
-    const double jph_s = (sp_s + sp_ss) * 0.5;                                   // at (j+1,i)
-    const double pb_c = a.p[p_c + i], pb_e = a.p[p_c + ie], pb_s = a.p[p_s + i];
-    const double iph_pb = (pb_c + pb_e) * 0.5, jph_pb = (pb_c + pb_s) * 0.5;
-    const double pn_c = a.pn[p_c + i], pn_e = a.pn[p_c + ie], pn_s = a.pn[p_s + i];
-    const double inv_pnu = rcp((pn_c + pn_e) * 0.5), inv_pnv = rcp((pn_c + pn_s) * 0.5), inv_pn = rcp(pn_c);
+    const T sp_c = spr[p_c + i], sp_e = spr[p_c + ie];
+    const T sp_s = spr[p_s + i], sp_se = spr[p_s + ie], sp_ss = spr[p_ss + i];
+    const T sp_n = spr[p_n + i], sp_ne = spr[p_n + ie];
+    const T jph_c = (sp_c + sp_s) * T(0.5), jph_ce = (sp_e + sp_se) * T(0.5);     // jph(sp) at (j,i),(j,i+1)
+    const T jph_n = (sp_n + sp_c) * T(0.5), jph_ne = (sp_ne + sp_e) * T(0.5);     // at (j-1,i),(j-1,i+1)
+    const T jph_s = (sp_s + sp_ss) * T(0.5);                                   // at (j+1,i)
+    const T pb_c = a.p[p_c + i], pb_e = a.p[p_c + ie], pb_s = a.p[p_s + i];
+    const T iph_pb = (pb_c + pb_e) * T(0.5), jph_pb = (pb_c + pb_s) * T(0.5);
+    const T pn_c = a.pn[p_c + i], pn_e = a.pn[p_c + ie], pn_s = a.pn[p_s + i];
+    const T inv_pnu = rcp((pn_c + pn_e) * T(0.5)), inv_pnv = rcp((pn_c + pn_s) * T(0.5)), inv_pn = rcp(pn_c);
     const bool pole_edge = jg == a.Hg - 1;
     const bool coriolis = a.cor_u != nullptr;
-    const double cp_u = coriolis ? a.cor_u[jg] : 0.0, cp_v = coriolis ? a.cor_v[jg] : 0.0;
+    const T cp_u = coriolis ? a.cor_u[jg] : T(0.0), cp_v = coriolis ? a.cor_v[jg] : T(0.0);
     a.op[(long)j * W + i] = pn_c;
 
     // The levels are marched from the top down, because sigma-dot is the top-down running sum of
@@ -496,17 +524,17 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgs a) {
     // for this column and its east and south neighbours (iph(sd), jph(sd)), from the mass fluxes
     // the momentum advection loads anyway, instead of being read back from HBM.
     // Vertical window: level k+1 (p), k (c), k-1 (m).  kp()/km() wrap (coordinates_3d.py:55-60):
-    // level L is 0 and level -1 is L-1; both only ever meet sd[0] = 0.
-    const double inv_dxj_s = a.inv_dxj[wrapi(a.row0 + j + 1, a.Hg)];
-    const double pit_c = a.pit[p_c + i], pit_e = a.pit[p_c + ie], pit_s = a.pit[p_s + i];
+    // level L is 0 and level -1 is L-1; both only ever meet sd[0] = T(0.)
+    const T inv_dxj_s = a.inv_dxj[wrapi(a.row0 + j + 1, a.Hg)];
+    const T pit_c = a.pit[p_c + i], pit_e = a.pit[p_c + ie], pit_s = a.pit[p_s + i];
     const long top = (long)(L - 1) * W;
-    double su_p = a.su[rc + i], sv_p = a.sv[rc + i], st_p = a.st[rc + i], sq_p = a.sq[rc + i];   // level L -> 0
-    double su_c = a.su[rc + top + i], sv_c = a.sv[rc + top + i], st_c = a.st[rc + top + i], sq_c = a.sq[rc + top + i];
-    double sd_cp = 0.0, sd_ep = 0.0, sd_sp = 0.0;            // sd at level k+1; level L wraps to sd[0] = 0
-    double rc_c = 0.0, rc_e = 0.0, rc_s = 0.0;               // running sums of conv from the top
+    T su_p = a.su[rc + i], sv_p = a.sv[rc + i], st_p = a.st[rc + i], sq_p = a.sq[rc + i];   // level L -> 0
+    T su_c = a.su[rc + top + i], sv_c = a.sv[rc + top + i], st_c = a.st[rc + top + i], sq_c = a.sq[rc + top + i];
+    T sd_cp = T(0.0), sd_ep = T(0.0), sd_sp = T(0.0);            // sd at level k+1; level L wraps to sd[0] = 0
+    T rc_c = T(0.0), rc_e = T(0.0), rc_s = T(0.0);               // running sums of conv from the top
     for (int k = L - 1; k >= 0; --k) {
         const long kc = (long)k * W;
-        double su_m, sv_m, st_m, sq_m;
+        T su_m, sv_m, st_m, sq_m;
         if (k > 0) {
             const long kmo = kc - W;
             su_m = a.su[rc + kmo + i]; sv_m = a.sv[rc + kmo + i]; st_m = a.st[rc + kmo + i]; sq_m = a.sq[rc + kmo + i];
@@ -514,19 +542,19 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgs a) {
             su_m = a.su[rc + top + i]; sv_m = a.sv[rc + top + i]; st_m = a.st[rc + top + i]; sq_m = a.sq[rc + top + i];
         }
         // stage winds, horizontal neighbours
-        const double su_w = a.su[rc + kc + iw], su_e = a.su[rc + kc + ie];
-        const double su_n = a.su[rn + kc + i], su_s = a.su[rs + kc + i];
-        const double sv_w = a.sv[rc + kc + iw], sv_e = a.sv[rc + kc + ie];
-        const double sv_n = a.sv[rn + kc + i], sv_ne = a.sv[rn + kc + ie], sv_s = a.sv[rs + kc + i];
+        const T su_w = a.su[rc + kc + iw], su_e = a.su[rc + kc + ie];
+        const T su_n = a.su[rn + kc + i], su_s = a.su[rs + kc + i];
+        const T sv_w = a.sv[rc + kc + iw], sv_e = a.sv[rc + kc + ie];
+        const T sv_n = a.sv[rn + kc + i], sv_ne = a.sv[rn + kc + ie], sv_s = a.sv[rs + kc + i];
         // mass fluxes: spu filtered (K1); spv = sv * jph(sp), dynamics.py:20-22
-        const double spu_c = a.spu[rc + kc + i], spu_w = a.spu[rc + kc + iw], spu_e = a.spu[rc + kc + ie];
-        const double spu_s = a.spu[rs + kc + i], spu_sw = a.spu[rs + kc + iw];
-        const double spv_c = sv_c * jph_c, spv_e = sv_e * jph_ce;
-        const double spv_n = sv_n * jph_n, spv_ne = sv_ne * jph_ne;
-        const double spv_s = sv_s * jph_s;
+        const T spu_c = a.spu[rc + kc + i], spu_w = a.spu[rc + kc + iw], spu_e = a.spu[rc + kc + ie];
+        const T spu_s = a.spu[rs + kc + i], spu_sw = a.spu[rs + kc + iw];
+        const T spv_c = sv_c * jph_c, spv_e = sv_e * jph_ce;
+        const T spv_n = sv_n * jph_n, spv_ne = sv_ne * jph_ne;
+        const T spv_s = sv_s * jph_s;
         // ---- aflux, dynamics.py:35-46, at (j,i), (j,i+1), (j+1,i)
-        const double dsg = a.dsig[k], sgb = a.sigb[k];
-        double sd_c = 0.0, sd_e = 0.0, sd_s = 0.0;           // sd[0] = 0, dynamics.py:44
+        const T dsg = a.dsig[k], sgb = a.sigb[k];
+        T sd_c = T(0.0), sd_e = T(0.0), sd_s = T(0.0);           // sd[0] = 0, dynamics.py:44
         if (k > 0) {
             rc_c += ((spu_c - spu_w) * inv_dxj + (spv_c - spv_n) * inv_dy) * dsg;
             rc_e += ((spu_e - spu_c) * inv_dxj + (spv_e - spv_ne) * inv_dy) * dsg;
@@ -536,57 +564,57 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgs a) {
             sd_s = rc_s - pit_s * sgb;
         }
         // ---- advec_m_pu, dynamics.py:55-108
-        const double puum = ((su_c + su_w) * 0.5) * ((spu_c + spu_w) * 0.5);
-        const double puup = ((su_e + su_c) * 0.5) * ((spu_e + spu_c) * 0.5);
-        const double puvp = ((spv_c + spv_e) * 0.5) * ((su_c + su_s) * 0.5);
-        const double puvm = ((spv_n + spv_ne) * 0.5) * ((su_n + su_c) * 0.5);
-        const double pvvm = ((sv_c + sv_n) * 0.5) * ((spv_c + spv_n) * 0.5);
-        const double pvvp = ((sv_s + sv_c) * 0.5) * ((spv_s + spv_c) * 0.5);
-        const double pvup = ((sv_c + sv_e) * 0.5) * ((spu_c + spu_s) * 0.5);
-        const double pvum = ((sv_w + sv_c) * 0.5) * ((spu_w + spu_sw) * 0.5);
-        double cor_u = 0.0, cor_v = 0.0;                         // the reference adds a literal 0
+        const T puum = ((su_c + su_w) * T(0.5)) * ((spu_c + spu_w) * T(0.5));
+        const T puup = ((su_e + su_c) * T(0.5)) * ((spu_e + spu_c) * T(0.5));
+        const T puvp = ((spv_c + spv_e) * T(0.5)) * ((su_c + su_s) * T(0.5));
+        const T puvm = ((spv_n + spv_ne) * T(0.5)) * ((su_n + su_c) * T(0.5));
+        const T pvvm = ((sv_c + sv_n) * T(0.5)) * ((spv_c + spv_n) * T(0.5));
+        const T pvvp = ((sv_s + sv_c) * T(0.5)) * ((spv_s + spv_c) * T(0.5));
+        const T pvup = ((sv_c + sv_e) * T(0.5)) * ((spu_c + spu_s) * T(0.5));
+        const T pvum = ((sv_w + sv_c) * T(0.5)) * ((spu_w + spu_sw) * T(0.5));
+        T cor_u = T(0.0), cor_v = T(0.0);                         // the reference adds a literal 0
         if (coriolis) {                                          // dynamics.py:83-92
-            const double pu_at_pv = (((spu_c + spu_s) * 0.5) + ((spu_w + spu_sw) * 0.5)) * 0.5;    // imh(jph(pu))
-            const double pv_at_pu = (((spv_c + spv_n) * 0.5) + ((spv_e + spv_ne) * 0.5)) * 0.5;    // iph(jmh(pv))
+            const T pu_at_pv = (((spu_c + spu_s) * T(0.5)) + ((spu_w + spu_sw) * T(0.5))) * T(0.5);    // imh(jph(pu))
+            const T pv_at_pu = (((spv_c + spv_n) * T(0.5)) + ((spv_e + spv_ne) * T(0.5))) * T(0.5);    // iph(jmh(pv))
             cor_u = cp_u * -pv_at_pu;
             cor_v = cp_v * pu_at_pv;
         }
-        const double dut = (puum - puup) * inv_dxj + (puvm - puvp) * inv_dy + cor_u;
-        const double dvt = (pvvm - pvvp) * inv_dy + (pvum - pvup) * inv_dxh + cor_v;
+        const T dut = (puum - puup) * inv_dxj + (puvm - puvp) * inv_dy + cor_u;
+        const T dvt = (pvvm - pvvp) * inv_dy + (pvum - pvup) * inv_dxh + cor_v;
         // ---- pgf v-part, dynamics.py:160,167-169 (the u-part went through K3)
-        const double sg = a.sig[k];
-        const double phi_c = a.phi[rc + kc + i], phi_s = a.phi[rs + kc + i];
-        const double rho_c = a.rho[rc + kc + i], rho_s = a.rho[rs + kc + i];
-        const double phiv = jph_c * ((phi_s - phi_c) * inv_dy);
-        const double pgv = ((sg * sp_c + sg * sp_s) * 0.5) * rcp((rho_c + rho_s) * 0.5) * ((sp_s - sp_c) * inv_dy);
+        const T sg = a.sig[k];
+        const T phi_c = a.phi[rc + kc + i], phi_s = a.phi[rs + kc + i];
+        const T rho_c = a.rho[rc + kc + i], rho_s = a.rho[rs + kc + i];
+        const T phiv = jph_c * ((phi_s - phi_c) * inv_dy);
+        const T pgv = ((sg * sp_c + sg * sp_s) * T(0.5)) * rcp((rho_c + rho_s) * T(0.5)) * ((sp_s - sp_c) * inv_dy);
         // ---- vertical advection, dynamics.py:49-52 with iph(sd), jph(sd), sd
-        const double inv_ds = a.inv_dsig[k];
-        const double sdi = (sd_c + sd_e) * 0.5, sdi_p = (sd_cp + sd_ep) * 0.5;
-        const double sdj = (sd_c + sd_s) * 0.5, sdj_p = (sd_cp + sd_sp) * 0.5;
-        const double dus = -((((su_c + su_m) * 0.5) * sdi - ((su_p + su_c) * 0.5) * sdi_p) * inv_ds);
-        const double dvs = -((((sv_c + sv_m) * 0.5) * sdj - ((sv_p + sv_c) * 0.5) * sdj_p) * inv_ds);
-        const double dts = -((((st_c + st_m) * 0.5) * sd_c - ((st_p + st_c) * 0.5) * sd_cp) * inv_ds);
-        const double dqs = -((((sq_c + sq_m) * 0.5) * sd_c - ((sq_p + sq_c) * 0.5) * sd_cp) * inv_ds);
+        const T inv_ds = a.inv_dsig[k];
+        const T sdi = (sd_c + sd_e) * T(0.5), sdi_p = (sd_cp + sd_ep) * T(0.5);
+        const T sdj = (sd_c + sd_s) * T(0.5), sdj_p = (sd_cp + sd_sp) * T(0.5);
+        const T dus = -((((su_c + su_m) * T(0.5)) * sdi - ((su_p + su_c) * T(0.5)) * sdi_p) * inv_ds);
+        const T dvs = -((((sv_c + sv_m) * T(0.5)) * sdj - ((sv_p + sv_c) * T(0.5)) * sdj_p) * inv_ds);
+        const T dts = -((((st_c + st_m) * T(0.5)) * sd_c - ((st_p + st_c) * T(0.5)) * sd_cp) * inv_ds);
+        const T dqs = -((((sq_c + sq_m) * T(0.5)) * sd_c - ((sq_p + sq_c) * T(0.5)) * sd_cp) * inv_ds);
         // ---- momentum update, dynamics.py:186-212
-        const double pu = a.u[rc + kc + i] * iph_pb;
-        const double pv = a.v[rc + kc + i] * jph_pb;
-        const double pgfu = a.pgfu[rc + kc + i];
-        const double pu_n = pu - (dut + dus + pgfu) * dt;
-        const double pv_n = pv - (dvt + dvs + phiv + pgv) * dt;
-        double u_n = pu_n * inv_pnu;
-        double v_n = pv_n * inv_pnv;
-        if (pole_edge) v_n *= 0.0;                               // v_n[:, -1, :] *= 0, dynamics.py:222
+        const T pu = a.u[rc + kc + i] * iph_pb;
+        const T pv = a.v[rc + kc + i] * jph_pb;
+        const T pgfu = a.pgfu[rc + kc + i];
+        const T pu_n = pu - (dut + dus + pgfu) * dt;
+        const T pv_n = pv - (dvt + dvs + phiv + pgv) * dt;
+        T u_n = pu_n * inv_pnu;
+        T v_n = pv_n * inv_pnv;
+        if (pole_edge) v_n *= T(0.0);                               // v_n[:, -1, :] *= 0, dynamics.py:222
         // ---- advec_t for t and q, dynamics.py:174-181,214-219
-        const double st_e = a.st[rc + kc + ie], st_w = a.st[rc + kc + iw];
-        const double st_s = a.st[rs + kc + i], st_n = a.st[rn + kc + i];
-        const double sq_e = a.sq[rc + kc + ie], sq_w = a.sq[rc + kc + iw];
-        const double sq_s = a.sq[rs + kc + i], sq_n = a.sq[rn + kc + i];
-        const double adt = (spu_c * ((st_c + st_e) * 0.5) - spu_w * ((st_w + st_c) * 0.5)) * inv_dxj +
-                           (spv_c * ((st_c + st_s) * 0.5) - spv_n * ((st_n + st_c) * 0.5)) * inv_dy;
-        const double adq = (spu_c * ((sq_c + sq_e) * 0.5) - spu_w * ((sq_w + sq_c) * 0.5)) * inv_dxj +
-                           (spv_c * ((sq_c + sq_s) * 0.5) - spv_n * ((sq_n + sq_c) * 0.5)) * inv_dy;
-        const double t_n = (a.t[rc + kc + i] * pb_c - (adt + dts) * dt) * inv_pn;
-        const double q_n = (a.q[rc + kc + i] * pb_c - (adq + dqs) * dt) * inv_pn;
+        const T st_e = a.st[rc + kc + ie], st_w = a.st[rc + kc + iw];
+        const T st_s = a.st[rs + kc + i], st_n = a.st[rn + kc + i];
+        const T sq_e = a.sq[rc + kc + ie], sq_w = a.sq[rc + kc + iw];
+        const T sq_s = a.sq[rs + kc + i], sq_n = a.sq[rn + kc + i];
+        const T adt = (spu_c * ((st_c + st_e) * T(0.5)) - spu_w * ((st_w + st_c) * T(0.5))) * inv_dxj +
+                           (spv_c * ((st_c + st_s) * T(0.5)) - spv_n * ((st_n + st_c) * T(0.5))) * inv_dy;
+        const T adq = (spu_c * ((sq_c + sq_e) * T(0.5)) - spu_w * ((sq_w + sq_c) * T(0.5))) * inv_dxj +
+                           (spv_c * ((sq_c + sq_s) * T(0.5)) - spv_n * ((sq_n + sq_c) * T(0.5))) * inv_dy;
+        const T t_n = (a.t[rc + kc + i] * pb_c - (adt + dts) * dt) * inv_pn;
+        const T q_n = (a.q[rc + kc + i] * pb_c - (adq + dqs) * dt) * inv_pn;
         const long o = (long)j * L * W + kc + i;                 // interior rows: no wrap needed
         a.ou[o] = u_n;
         a.ov[o] = v_n;
@@ -598,6 +626,8 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgs a) {
         sd_cp = sd_c; sd_ep = sd_e; sd_sp = sd_s;
     }
 }
+
+using PeArgs = PeArgsT<double>;   // the diagnostics and the column physics below are fp64 only
 
 // ---------------------------------------------------------------- calc_energy (no_limits_2_5d.py:35-60)
 // thread per (j,i) column; out[4*block + {0,1,2}] = partial sums of ke, ate, geo
@@ -715,43 +745,54 @@ __global__ __launch_bounds__(256) void pe_radiation_kernel(PeArgs a, RadArgs r, 
 }
 
 // ---------------------------------------------------------------- layout transposes
-// host layout [k][j][i] (rows of THIS band only) <-> device [j][k][i]
-__global__ void pe_to_device_kernel(double *dst, const double *src, int W, int H, int L) {
+// host layout [k][j][i] (rows of THIS band only, always float64) <-> device [j][k][i] in the
+// handle's real type
+template <typename T>
+__global__ void pe_to_device_kernel(T *dst, const double *src, int W, int H, int L) {
     const long n = (long)W * H * L;
     for (long x = (long)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (long)gridDim.x * blockDim.x) {
         const int i = x % W;
         const long r = x / W;
         const int k = r % L, j = r / L;
-        dst[x] = src[((long)k * H + j) * W + i];
+        dst[x] = (T)src[((long)k * H + j) * W + i];
     }
 }
-__global__ void pe_to_host_kernel(double *dst, const double *src, int W, int H, int L) {
+template <typename T>
+__global__ void pe_to_host_kernel(double *dst, const T *src, int W, int H, int L) {
     const long n = (long)W * H * L;
     for (long x = (long)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (long)gridDim.x * blockDim.x) {
         const int i = x % W;
         const long r = x / W;
         const int k = r % L, j = r / L;
-        dst[((long)k * H + j) * W + i] = src[x];
+        dst[((long)k * H + j) * W + i] = (double)src[x];
     }
 }
 
 // ================================================================== host side
+// Device buffers in the handle's real type T (fp64, or fp32 for the tolerance sweep).
+template <typename T>
+struct PeBufs {
+    using T2 = typename Vec2<T>::type;
+    // state sets: 0/1 ping-pong (cur = set[cur_i]), 2 = star.  [f] p,u,v,t,q; interior pointers
+    T *st[3][GCM_NFIELDS] = {};
+    T *spu = nullptr, *phi = nullptr, *rho = nullptr, *pgfu = nullptr, *pit = nullptr, *pn = nullptr;
+    T *cor_u = nullptr, *cor_v = nullptr;
+    T *inv_dxj = nullptr, *inv_dxh = nullptr, *sig = nullptr, *dsig = nullptr, *inv_dsig = nullptr,
+      *sigb = nullptr, *sigt = nullptr, *heightmap = nullptr, *smul = nullptr;
+    T2 *tw = nullptr;
+};
+
 struct Pe25d {
     gcm_config cfg{};
     int W = 0, H = 0, L = 0, Hg = 0;
-    bool wrap = true;
+    bool wrap = true, f32 = false;
     std::vector<void *> allocs;
-    // state sets: 0/1 ping-pong (cur = set[cur_i]), 2 = star.  [f] p,u,v,t,q; interior pointers
-    double *st[3][GCM_NFIELDS] = {};
+    PeBufs<double> d;
+    PeBufs<float> f;
     int cur_i = 0;
     bool star_valid = false;
-    double *spu = nullptr, *phi = nullptr, *rho = nullptr, *pgfu = nullptr;
-    double *pit = nullptr, *pn = nullptr, *stage3 = nullptr;  // stage3: transpose staging
-    double *cor_u = nullptr, *cor_v = nullptr;
-    double *inv_dxj = nullptr, *inv_dxh = nullptr, *sig = nullptr, *dsig = nullptr,
-           *inv_dsig = nullptr, *sigb = nullptr, *sigt = nullptr, *heightmap = nullptr,
-           *smul = nullptr, *exner_tab = nullptr;
-    double2 *tw = nullptr;
+    double *stage3 = nullptr;                   // float64 transpose staging, host layout
+    double *exner_tab = nullptr;
     FftPlan plan{};
     double *gt = nullptr;                       // ground temperature [H][W] (column physics)
     double *rad_tab = nullptr;                  // 5 x [L] level tables of the last radiation call
@@ -760,6 +801,10 @@ struct Pe25d {
     std::vector<hipEvent_t> *ev = nullptr;
     size_t *ev_used = nullptr;
 };
+
+template <typename T> static PeBufs<T> &bufs(Pe25d *m);
+template <> PeBufs<double> &bufs<double>(Pe25d *m) { return m->d; }
+template <> PeBufs<float> &bufs<float>(Pe25d *m) { return m->f; }
 
 static bool make_plan(int n, FftPlan *P) {
     P->n = n;
@@ -792,7 +837,85 @@ static bool dev_upload(Pe25d *m, T **dst, const T *src, size_t count) {
     return true;
 }
 
+// host float64 table -> device table in T
+template <typename T>
+static bool upload_as(Pe25d *m, T **dst, const double *src, size_t count) {
+    std::vector<T> tmp(count);
+    for (size_t i = 0; i < count; ++i) tmp[i] = (T)src[i];
+    return dev_upload<T>(m, dst, tmp.data(), count);
+}
+
 static size_t rows_alloc(const Pe25d *m) { return (size_t)m->H + 2 * kGhost; }
+
+template <typename T>
+static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
+    PeBufs<T> &B = bufs<T>(m);
+    const int W = m->W, L = m->L, Hg = m->Hg;
+    const size_t n2 = rows_alloc(m) * W, n3 = n2 * L;
+    for (int s = 0; s < 3; ++s)
+        for (int f = 0; f < GCM_NFIELDS; ++f) {
+            T *d = nullptr;
+            if (!dev_upload<T>(m, &d, nullptr, f == GCM_P ? n2 : n3)) return "state";
+            B.st[s][f] = d + (size_t)kGhost * W * (f == GCM_P ? 1 : L);
+        }
+    T **inter3[] = {&B.spu, &B.phi, &B.rho, &B.pgfu};
+    for (T **pp : inter3) {
+        T *d = nullptr;
+        if (!dev_upload<T>(m, &d, nullptr, n3)) return "intermediate";
+        *pp = d + (size_t)kGhost * W * L;
+    }
+    T **inter2[] = {&B.pit, &B.pn};
+    for (T **pp : inter2) {
+        T *d = nullptr;
+        if (!dev_upload<T>(m, &d, nullptr, n2)) return "intermediate";
+        *pp = d + (size_t)kGhost * W;
+    }
+    // tables
+    std::vector<double> idj(Hg), idh(Hg), ids(L);
+    for (int j = 0; j < Hg; ++j) {
+        idj[j] = 1.0 / cfg.dx_j[j];
+        idh[j] = 1.0 / cfg.dx_h[j];
+    }
+    for (int k = 0; k < L; ++k) ids[k] = 1.0 / cfg.dsig[k];
+    if (!upload_as<T>(m, &B.inv_dxj, idj.data(), Hg) || !upload_as<T>(m, &B.inv_dxh, idh.data(), Hg) ||
+        !upload_as<T>(m, &B.sig, cfg.sig, L) || !upload_as<T>(m, &B.dsig, cfg.dsig, L) ||
+        !upload_as<T>(m, &B.inv_dsig, ids.data(), L) || !upload_as<T>(m, &B.sigb, cfg.sigb, L) ||
+        !upload_as<T>(m, &B.sigt, cfg.sigt, L))
+        return "tables";
+    if (cfg.heightmap && !upload_as<T>(m, &B.heightmap, cfg.heightmap, (size_t)Hg * W)) return "heightmap";
+    if (cfg.cor_u && (!upload_as<T>(m, &B.cor_u, cfg.cor_u, Hg) || !upload_as<T>(m, &B.cor_v, cfg.cor_v, Hg)))
+        return "coriolis tables";
+    if (W > 1) {
+        // filter multiplier, low_pass.py:61-72, same expression order as the reference
+        const int nh = W / 2 + 1;
+        std::vector<double> S((size_t)Hg * nh);
+        for (int j = 0; j < Hg; ++j) {
+            const double drat = cfg.dy / cfg.dx_j[j];
+            S[(size_t)j * nh] = 1.0;
+            for (int n = 1; n < nh; ++n) {
+                const double bysn = 1.0 / std::sin(M_PI / W * (double)n);
+                const double sm = 1.0 - bysn / drat;
+                S[(size_t)j * nh + n] = 1.0 - std::fmax(sm, 0.0);
+            }
+        }
+        if (!upload_as<T>(m, &B.smul, S.data(), S.size())) return "filter multiplier";
+        using T2 = typename Vec2<T>::type;
+        std::vector<T2> tw(W);
+        for (int n = 0; n < W; ++n) {
+            const long double ang = -2.0L * 3.14159265358979323846264338327950288L * n / W;
+            tw[n].x = (T)cosl(ang);
+            tw[n].y = (T)sinl(ang);
+        }
+        if (!dev_upload<T2>(m, &B.tw, tw.data(), W)) return "twiddles";
+    }
+    const int lds_bytes = 2 * W * (int)sizeof(typename Vec2<T>::type);
+    if (hipFuncSetAttribute((const void *)pe_spu_filter_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void *)pe_pgf_filter_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void *)pe_column_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(L * kColThreads * sizeof(T))) != hipSuccess)
+        return "dynamic LDS size";
+    return nullptr;
+}
 
 Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
     if (!cfg.dx_j || !cfg.dx_h || !cfg.sig || !cfg.dsig || !cfg.sigb || !cfg.sigt) {
@@ -812,6 +935,11 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
         *err = "GCM_PE25D: the zonal filter needs an even width (low_pass.py:57; numpy irfft)";
         return nullptr;
     }
+    if ((cfg.cor_u != nullptr) != (cfg.cor_v != nullptr)) {
+        *err = "GCM_PE25D: cor_u and cor_v must be given together";
+        return nullptr;
+    }
+    if (cfg.dtype != GCM_F64 && cfg.dtype != GCM_F32) { *err = "GCM_PE25D: bad dtype"; return nullptr; }
     Pe25d *m = new Pe25d;
     m->cfg = cfg;
     m->W = cfg.width;
@@ -819,7 +947,8 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
     m->L = cfg.layers;
     m->Hg = cfg.global_height;
     m->wrap = cfg.nranks == 1;
-    const int W = m->W, L = m->L, Hg = m->Hg;
+    m->f32 = cfg.dtype == GCM_F32;
+    const int W = m->W, L = m->L;
     auto bad = [&](const char *what) {
         *err = std::string("hip: GCM_PE25D allocation/upload failed: ") + what;
         pe25d_destroy(m);
@@ -830,84 +959,16 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
         pe25d_destroy(m);
         return nullptr;
     }
-    const size_t n2 = rows_alloc(m) * W, n3 = n2 * L;
-    for (int s = 0; s < 3; ++s)
-        for (int f = 0; f < GCM_NFIELDS; ++f) {
-            double *d = nullptr;
-            const size_t n = f == GCM_P ? n2 : n3;
-            if (!dev_upload<double>(m, &d, nullptr, n)) return bad("state");
-            m->st[s][f] = d + (size_t)kGhost * W * (f == GCM_P ? 1 : L);
-        }
-    double **inter3[] = {&m->spu, &m->phi, &m->rho, &m->pgfu};
-    for (double **pp : inter3) {
-        double *d = nullptr;
-        if (!dev_upload<double>(m, &d, nullptr, n3)) return bad("intermediate");
-        *pp = d + (size_t)kGhost * W * L;
-    }
-    double **inter2[] = {&m->pit, &m->pn};
-    for (double **pp : inter2) {
-        double *d = nullptr;
-        if (!dev_upload<double>(m, &d, nullptr, n2)) return bad("intermediate");
-        *pp = d + (size_t)kGhost * W;
-    }
-    if (!dev_upload<double>(m, &m->stage3, nullptr, (size_t)m->H * W * L)) return bad("staging");
-    // tables
-    std::vector<double> idj(Hg), idh(Hg), ids(L);
-    for (int j = 0; j < Hg; ++j) {
-        idj[j] = 1.0 / cfg.dx_j[j];
-        idh[j] = 1.0 / cfg.dx_h[j];
-    }
-    for (int k = 0; k < L; ++k) ids[k] = 1.0 / cfg.dsig[k];
-    if (!dev_upload(m, &m->inv_dxj, idj.data(), Hg) || !dev_upload(m, &m->inv_dxh, idh.data(), Hg) ||
-        !dev_upload(m, &m->sig, cfg.sig, L) || !dev_upload(m, &m->dsig, cfg.dsig, L) ||
-        !dev_upload(m, &m->inv_dsig, ids.data(), L) || !dev_upload(m, &m->sigb, cfg.sigb, L) ||
-        !dev_upload(m, &m->sigt, cfg.sigt, L))
-        return bad("tables");
-    if (cfg.heightmap && !dev_upload(m, &m->heightmap, cfg.heightmap, (size_t)Hg * W))
-        return bad("heightmap");
-    if ((cfg.cor_u != nullptr) != (cfg.cor_v != nullptr)) {
-        *err = "GCM_PE25D: cor_u and cor_v must be given together";
-        pe25d_destroy(m);
-        return nullptr;
-    }
-    if (cfg.cor_u && (!dev_upload(m, &m->cor_u, cfg.cor_u, Hg) || !dev_upload(m, &m->cor_v, cfg.cor_v, Hg)))
-        return bad("coriolis tables");
-    double tab[kExnerTabDoubles];
-    build_exner_table(tab);
-    if (!dev_upload(m, &m->exner_tab, tab, kExnerTabDoubles)) return bad("exner table");
-    const int lds_bytes = 2 * W * (int)sizeof(double2);
-    if (hipFuncSetAttribute((const void *)pe_spu_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute((const void *)pe_pgf_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
-        return bad("dynamic LDS size");
     if ((size_t)L * kColThreads * sizeof(double) + kExnerTabDoubles * sizeof(double) > 160 * 1024) {
         *err = "GCM_PE25D: too many layers for the column kernel's LDS (max 158)";
         pe25d_destroy(m);
         return nullptr;
     }
-    if (hipFuncSetAttribute((const void *)pe_column_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(L * kColThreads * sizeof(double))) != hipSuccess)
-        return bad("dynamic LDS size (column kernel)");
-    if (W > 1) {
-        // filter multiplier, low_pass.py:61-72, same expression order as the reference
-        const int nh = W / 2 + 1;
-        std::vector<double> S((size_t)Hg * nh);
-        for (int j = 0; j < Hg; ++j) {
-            const double drat = cfg.dy / cfg.dx_j[j];
-            S[(size_t)j * nh] = 1.0;
-            for (int n = 1; n < nh; ++n) {
-                const double bysn = 1.0 / std::sin(M_PI / W * (double)n);
-                const double sm = 1.0 - bysn / drat;
-                S[(size_t)j * nh + n] = 1.0 - std::fmax(sm, 0.0);
-            }
-        }
-        if (!dev_upload(m, &m->smul, S.data(), S.size())) return bad("filter multiplier");
-        std::vector<double2> tw(W);
-        for (int n = 0; n < W; ++n) {
-            const long double ang = -2.0L * 3.14159265358979323846264338327950288L * n / W;
-            tw[n] = make_double2((double)cosl(ang), (double)sinl(ang));
-        }
-        if (!dev_upload(m, &m->tw, tw.data(), W)) return bad("twiddles");
-    }
+    if (const char *what = m->f32 ? alloc_all<float>(m, cfg) : alloc_all<double>(m, cfg)) return bad(what);
+    if (!dev_upload<double>(m, &m->stage3, nullptr, (size_t)m->H * W * L)) return bad("staging");
+    double tab[kExnerTabDoubles];
+    build_exner_table(tab);
+    if (!dev_upload(m, &m->exner_tab, tab, kExnerTabDoubles)) return bad("exner table");
     return m;
 }
 
@@ -917,28 +978,28 @@ void pe25d_destroy(Pe25d *m) {
     delete m;
 }
 
-static int xfer(Pe25d *m, int set, bool to_dev, const double *const in[GCM_NFIELDS],
-                double *const out[GCM_NFIELDS], std::string *err) {
-    const int W = m->W, H = m->H, L = m->L;
-    const size_t b2 = sizeof(double) * (size_t)H * W, b3 = b2 * L;
+template <typename T>
+static int xfer_t(Pe25d *m, int set, bool to_dev, const double *const in[GCM_NFIELDS],
+                  double *const out[GCM_NFIELDS], std::string *err) {
+    PeBufs<T> &B = bufs<T>(m);
+    const int W = m->W, H = m->H;
     for (int f = 0; f < GCM_NFIELDS; ++f) {
         const void *hp = to_dev ? (const void *)in[f] : (const void *)out[f];
         if (!hp) continue;
+        const int L = f == GCM_P ? 1 : m->L;
+        const size_t bytes = sizeof(double) * (size_t)H * W * L;
         hipError_t e = hipSuccess;
-        if (f == GCM_P) {
-            e = to_dev ? hipMemcpy(m->st[set][f], in[f], b2, hipMemcpyHostToDevice)
-                       : hipMemcpy(out[f], m->st[set][f], b2, hipMemcpyDeviceToHost);
-        } else if (to_dev) {
-            e = hipMemcpy(m->stage3, in[f], b3, hipMemcpyHostToDevice);
+        if (to_dev) {
+            e = hipMemcpy(m->stage3, in[f], bytes, hipMemcpyHostToDevice);
             if (e == hipSuccess) {
-                hipLaunchKernelGGL(pe_to_device_kernel, dim3(1024), dim3(256), 0, nullptr, m->st[set][f],
+                hipLaunchKernelGGL(pe_to_device_kernel<T>, dim3(1024), dim3(256), 0, nullptr, B.st[set][f],
                                    m->stage3, W, H, L);
                 e = hipDeviceSynchronize();
             }
         } else {
-            hipLaunchKernelGGL(pe_to_host_kernel, dim3(1024), dim3(256), 0, nullptr, m->stage3,
-                               m->st[set][f], W, H, L);
-            e = hipMemcpy(out[f], m->stage3, b3, hipMemcpyDeviceToHost);
+            hipLaunchKernelGGL(pe_to_host_kernel<T>, dim3(1024), dim3(256), 0, nullptr, m->stage3,
+                               B.st[set][f], W, H, L);
+            e = hipMemcpy(out[f], m->stage3, bytes, hipMemcpyDeviceToHost);
         }
         if (e != hipSuccess) {
             *err = std::string("pe25d state transfer: ") + hipGetErrorString(e);
@@ -946,6 +1007,11 @@ static int xfer(Pe25d *m, int set, bool to_dev, const double *const in[GCM_NFIEL
         }
     }
     return GCM_OK;
+}
+
+static int xfer(Pe25d *m, int set, bool to_dev, const double *const in[GCM_NFIELDS],
+                double *const out[GCM_NFIELDS], std::string *err) {
+    return m->f32 ? xfer_t<float>(m, set, to_dev, in, out, err) : xfer_t<double>(m, set, to_dev, in, out, err);
 }
 
 int pe25d_set(Pe25d *m, bool star, const double *p, const double *u, const double *v,
@@ -968,26 +1034,29 @@ int pe25d_get(Pe25d *m, bool star, double *p, double *u, double *v, double *t, d
     return xfer(m, star ? 2 : m->cur_i, false, nullptr, out, err);
 }
 
-static PeArgs make_args(Pe25d *m, int stage_set, int out_set, double dt) {
-    PeArgs a{};
-    double *const *B = m->st[m->cur_i];
-    double *const *S = m->st[stage_set];
-    double *const *O = m->st[out_set];
+template <typename T>
+static PeArgsT<T> make_args(Pe25d *m, int stage_set, int out_set, double dt) {
+    PeBufs<T> &Bf = bufs<T>(m);
+    PeArgsT<T> a{};
+    T *const *B = Bf.st[m->cur_i];
+    T *const *S = Bf.st[stage_set];
+    T *const *O = Bf.st[out_set];
     a.p = B[GCM_P]; a.u = B[GCM_U]; a.v = B[GCM_V]; a.t = B[GCM_T]; a.q = B[GCM_Q];
     a.sp = S[GCM_P]; a.su = S[GCM_U]; a.sv = S[GCM_V]; a.st = S[GCM_T]; a.sq = S[GCM_Q];
     a.op = O[GCM_P]; a.ou = O[GCM_U]; a.ov = O[GCM_V]; a.ot = O[GCM_T]; a.oq = O[GCM_Q];
-    a.spu = m->spu; a.phi = m->phi; a.rho = m->rho; a.pgfu = m->pgfu;
-    a.pit = m->pit; a.pn = m->pn;
-    a.inv_dxj = m->inv_dxj; a.inv_dxh = m->inv_dxh;
-    a.sig = m->sig; a.dsig = m->dsig; a.inv_dsig = m->inv_dsig; a.sigb = m->sigb; a.sigt = m->sigt;
-    a.heightmap = m->heightmap; a.cor_u = m->cor_u; a.cor_v = m->cor_v; a.smul = m->smul; a.tw = m->tw; a.exner_tab = m->exner_tab;
+    a.spu = Bf.spu; a.phi = Bf.phi; a.rho = Bf.rho; a.pgfu = Bf.pgfu;
+    a.pit = Bf.pit; a.pn = Bf.pn;
+    a.inv_dxj = Bf.inv_dxj; a.inv_dxh = Bf.inv_dxh;
+    a.sig = Bf.sig; a.dsig = Bf.dsig; a.inv_dsig = Bf.inv_dsig; a.sigb = Bf.sigb; a.sigt = Bf.sigt;
+    a.heightmap = Bf.heightmap; a.cor_u = Bf.cor_u; a.cor_v = Bf.cor_v; a.smul = Bf.smul; a.tw = Bf.tw;
+    a.exner_tab = m->exner_tab;
     a.plan = m->plan;
     a.W = m->W; a.H = m->H; a.L = m->L; a.Hg = m->Hg; a.row0 = m->cfg.row0;
     a.wrap = m->wrap ? 1 : 0;
     a.filter = m->cfg.filter;
-    a.dt = dt;
-    a.inv_dy = 1.0 / m->cfg.dy;
-    a.ptop = m->cfg.ptop;
+    a.dt = (T)dt;
+    a.inv_dy = (T)(1.0 / m->cfg.dy);
+    a.ptop = (T)m->cfg.ptop;
     return a;
 }
 
@@ -996,29 +1065,35 @@ static void tick(Pe25d *m, hipStream_t s) {
 }
 
 // one Euler stage over rows [j0, j1): state `stage_set` -> `out_set`, base = current
-static void half(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1, hipStream_t s) {
+template <typename T>
+static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1, hipStream_t s) {
     if (j1 <= j0) return;
-    PeArgs a = make_args(m, stage_set, out_set, dt);
+    PeArgsT<T> a = make_args<T>(m, stage_set, out_set, dt);
     const int W = m->W, L = m->L;
     const int ext = m->wrap ? 0 : 1;             // intermediates are also needed on row j1 (south)
-    const size_t lds = (size_t)(m->plan.inplace ? 1 : 2) * W * sizeof(double2);
+    const size_t lds = (size_t)(m->plan.inplace ? 1 : 2) * W * sizeof(typename Vec2<T>::type);
     const int pairs = (L + 1) / 2;
     a.j0 = j0;
     a.j1 = j1 + ext;
-    hipLaunchKernelGGL(pe_spu_filter_kernel, dim3(a.j1 - a.j0, pairs), dim3(kFftThreads), lds, s, a);
+    hipLaunchKernelGGL(pe_spu_filter_kernel<T>, dim3(a.j1 - a.j0, pairs), dim3(kFftThreads), lds, s, a);
     {
         const long tiles = (long)((W + kColThreads - 1) / kColThreads) * (a.j1 - a.j0);
-        hipLaunchKernelGGL(pe_column_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kColThreads),
-                           sizeof(double) * (size_t)L * kColThreads, s, a);
+        hipLaunchKernelGGL(pe_column_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kColThreads),
+                           sizeof(T) * (size_t)L * kColThreads, s, a);
     }
     a.j1 = j1;
-    hipLaunchKernelGGL(pe_pgf_filter_kernel, dim3(a.j1 - a.j0, pairs), dim3(kFftThreads), lds, s, a);
+    hipLaunchKernelGGL(pe_pgf_filter_kernel<T>, dim3(a.j1 - a.j0, pairs), dim3(kFftThreads), lds, s, a);
     tick(m, s);
     {
         const long tiles = (long)((W + 255) / 256) * (a.j1 - a.j0);
-        hipLaunchKernelGGL(pe_update_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(pe_update_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, s, a);
     }
     tick(m, s);
+}
+
+static void half(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1, hipStream_t s) {
+    if (m->f32) half_t<float>(m, stage_set, out_set, dt, j0, j1, s);
+    else half_t<double>(m, stage_set, out_set, dt, j0, j1, s);
 }
 
 int pe25d_half(Pe25d *m, int stage, double dt, hipStream_t s, std::string *err) {
@@ -1086,25 +1161,37 @@ int pe25d_step_part(Pe25d *m, int part, double dt, hipStream_t s, std::string *e
 // ghost rows: [p: 2 rows][u,v,t,q: 2 rows x L levels]; contiguous in the device layout.
 // Which state is exchanged follows the step phase: the predicted state once it exists.
 size_t pe25d_halo_bytes(const Pe25d *m) {
-    return sizeof(double) * (size_t)kGhost * m->W * (1 + 4 * (size_t)m->L);
+    return (m->f32 ? sizeof(float) : sizeof(double)) * (size_t)kGhost * m->W * (1 + 4 * (size_t)m->L);
 }
 
-int pe25d_halo(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s, std::string *err) {
+template <typename T>
+static void halo_t(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s) {
+    PeBufs<T> &Bf = bufs<T>(m);
     const int set = m->star_valid ? 2 : m->cur_i;
-    double *b = (double *)dev_buf;
+    T *b = (T *)dev_buf;
     SegCopy c{};
     for (int f = 0; f < GCM_NFIELDS; ++f) {
         const size_t per_row = (size_t)m->W * (f == GCM_P ? 1 : m->L);
         const long n = (long)(kGhost * per_row);
-        double *base = m->st[set][f];
-        double *edge = side == 0 ? base : base + (size_t)(m->H - kGhost) * per_row;
-        double *ghost = side == 0 ? base - (size_t)kGhost * per_row : base + (size_t)m->H * per_row;
-        c.src[c.nseg] = pack ? edge : b;
-        c.dst[c.nseg] = pack ? b : ghost;
-        c.n[c.nseg++] = n;
+        T *base = Bf.st[set][f];
+        T *edge = side == 0 ? base : base + (size_t)(m->H - kGhost) * per_row;
+        T *ghost = side == 0 ? base - (size_t)kGhost * per_row : base + (size_t)m->H * per_row;
+        // SegCopy moves 8-byte words: 2 rows x (even W) floats is a whole number of them
+        c.src[c.nseg] = (const double *)(pack ? edge : b);
+        c.dst[c.nseg] = (double *)(pack ? b : ghost);
+        c.n[c.nseg++] = n * (long)sizeof(T) / 8;
         b += n;
     }
     launch_seg_copy(c, s);
+}
+
+int pe25d_halo(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s, std::string *err) {
+    if (m->f32 && (m->W % 2)) {
+        *err = "pe25d halo: fp32 bands need an even width";
+        return GCM_ERR_UNSUPPORTED;
+    }
+    if (m->f32) halo_t<float>(m, pack, side, dev_buf, s);
+    else halo_t<double>(m, pack, side, dev_buf, s);
     if (hipGetLastError() != hipSuccess) {
         *err = "hip: pe25d halo copy launch failed";
         return GCM_ERR_HIP;
@@ -1134,6 +1221,7 @@ int pe25d_ground(Pe25d *m, bool set, const double *in, double *out, std::string 
 int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, double t_sw, double albedo,
                     const double *lat, const double *lon, double *dTdt_host, double *dtg_host,
                     hipStream_t s, std::string *err) {
+    if (m->f32) { *err = "radiation: fp64 handles only"; return GCM_ERR_UNSUPPORTED; }
     if (!m->gt) { *err = "radiation: set the ground temperature first (gcm_set_ground)"; return GCM_ERR_STATE; }
     if (!lat || !lon) { *err = "radiation: lat and lon tables are required"; return GCM_ERR_ARG; }
     const int W = m->W, H = m->H, L = m->L, Hg = m->Hg;
@@ -1141,7 +1229,7 @@ int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, do
     if (m->rad_key[0] != t_lw || m->rad_key[1] != t_sw || !m->rad_tab) {
         // level tables, same expression order as grey_solar.py:323-333,377-385,541
         std::vector<double> T((size_t)5 * L), dsig(L);
-        if (hipMemcpy(dsig.data(), m->dsig, sizeof(double) * L, hipMemcpyDeviceToHost) != hipSuccess) {
+        if (hipMemcpy(dsig.data(), m->d.dsig, sizeof(double) * L, hipMemcpyDeviceToHost) != hipSuccess) {
             *err = "hip: radiation table read-back failed"; return GCM_ERR_HIP;
         }
         double *tlw = T.data(), *tsw = tlw + L, *csw = tsw + L, *cdiv = csw + L, *swf = cdiv + L;
@@ -1172,21 +1260,21 @@ int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, do
             *err = "hip: radiation geometry upload failed"; return GCM_ERR_HIP;
         }
     }
-    PeArgs a = make_args(m, m->cur_i, m->cur_i, dt);
+    PeArgs a = make_args<double>(m, m->cur_i, m->cur_i, dt);
     RadArgs r{};
     r.tlw = m->rad_tab; r.tsw = r.tlw + L; r.csw_top = r.tsw + L; r.clw_b_div = r.csw_top + L; r.swfac = r.clw_b_div + L;
     r.coslat = m->rad_geo; r.sinlat = m->rad_geo + Hg; r.lon = m->rad_geo + 2 * Hg;
     r.gt = m->gt;
-    r.emis = m->spu; r.lwb = m->phi; r.ttp = m->rho; r.dTdt = m->pgfu; r.dtg = m->pit;
+    r.emis = m->d.spu; r.lwb = m->d.phi; r.ttp = m->d.rho; r.dTdt = m->d.pgfu; r.dtg = m->d.pit;
     r.hour_angle = utc / (-24 * 3600.0) * 360 * (M_PI / 180);      // grey_solar.py:51
     r.albedo = albedo; r.dt = dt; r.apply = apply ? 1 : 0;
-    hipLaunchKernelGGL(pe_radiation_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, a, r, m->st[m->cur_i][GCM_T]);
+    hipLaunchKernelGGL(pe_radiation_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, a, r, m->d.st[m->cur_i][GCM_T]);
     if (hipStreamSynchronize(s) != hipSuccess) { *err = "hip: radiation kernel failed"; return GCM_ERR_HIP; }
-    if (dtg_host && hipMemcpy(dtg_host, m->pit, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (dtg_host && hipMemcpy(dtg_host, m->d.pit, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost) != hipSuccess) {
         *err = "hip: dt_ground copy-back failed"; return GCM_ERR_HIP;
     }
     if (dTdt_host) {
-        hipLaunchKernelGGL(pe_to_host_kernel, dim3(1024), dim3(256), 0, nullptr, m->stage3, m->pgfu, W, H, L);
+        hipLaunchKernelGGL(pe_to_host_kernel<double>, dim3(1024), dim3(256), 0, nullptr, m->stage3, m->d.pgfu, W, H, L);
         if (hipMemcpy(dTdt_host, m->stage3, sizeof(double) * (size_t)H * W * L, hipMemcpyDeviceToHost) != hipSuccess) {
             *err = "hip: dTdt copy-back failed"; return GCM_ERR_HIP;
         }
@@ -1195,6 +1283,7 @@ int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, do
 }
 
 int pe25d_energy(Pe25d *m, const double *area_host, int area_len, double out[4], std::string *err) {
+    if (m->f32) { *err = "gcm_energy: fp64 handles only"; return GCM_ERR_UNSUPPORTED; }
     if (!m->wrap) { *err = "gcm_energy: single band only"; return GCM_ERR_UNSUPPORTED; }
     if (!(area_len == 1 || area_len == m->W)) {
         *err = "gcm_energy: geom.area (H,) must broadcast against the last axis W (no_limits_2_5d.py:49): "
@@ -1210,7 +1299,7 @@ int pe25d_energy(Pe25d *m, const double *area_host, int area_len, double out[4],
         return GCM_ERR_HIP;
     }
     (void)hipDeviceSynchronize();
-    PeArgs a = make_args(m, m->cur_i, m->cur_i, 0.0);
+    PeArgs a = make_args<double>(m, m->cur_i, m->cur_i, 0.0);
     hipLaunchKernelGGL(pe_energy_kernel, dim3(gx, m->H), dim3(256), 0, nullptr, a, d_area, area_len > 1 ? 1 : 0, d_out);
     std::vector<double> part((size_t)4 * nb);
     hipError_t e = hipMemcpy(part.data(), d_out, sizeof(double) * 4 * nb, hipMemcpyDeviceToHost);
@@ -1223,9 +1312,11 @@ int pe25d_energy(Pe25d *m, const double *area_host, int area_len, double out[4],
     return GCM_OK;
 }
 
-const double *pe25d_field(Pe25d *m, int field, long *n) {
+// current-state field for the diagnostics reductions; *f32 tells the element type
+const void *pe25d_field(Pe25d *m, int field, long *n, int *f32) {
     *n = (long)m->H * m->W * (field == GCM_P ? 1 : m->L);
-    return m->st[m->cur_i][field];
+    *f32 = m->f32 ? 1 : 0;
+    return m->f32 ? (const void *)m->f.st[m->cur_i][field] : (const void *)m->d.st[m->cur_i][field];
 }
 
 void pe25d_timing(Pe25d *m, std::vector<hipEvent_t> *ev, size_t *used) {

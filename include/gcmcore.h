@@ -62,6 +62,8 @@ typedef enum {
                                build, see DESIGN.md                                               */
 } gcm_tracer;
 
+typedef enum { GCM_F64 = 0, GCM_F32 = 1 } gcm_dtype;
+
 /* Kernel variant (same arithmetic, different data movement). */
 typedef enum {
     GCM_VARIANT_AUTO = 0,
@@ -87,6 +89,8 @@ typedef struct {
     int32_t global_height;
     int32_t row0;
     int32_t device;        /* HIP device ordinal; -1 = current                                   */
+    int32_t dtype;         /* gcm_dtype: GCM_F64 (default) or GCM_F32 (GCM_PE25D only: arithmetic and
+                              storage in fp32 for the tolerance sweep; the host API stays float64) */
     int32_t halo_steps;    /* 2-D bands: Matsuno steps per ghost-row exchange (ghost depth = 2 *
                               halo_steps rows per side, deep-halo communication avoiding); 0/1 = 1 */
     double dx;             /* scalar grid spacing in metres (2-D models: both axes)              */

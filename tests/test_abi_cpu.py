@@ -38,7 +38,7 @@ def test_config_struct_layout_matches_header():
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     fields = re.findall(r"(?:int32_t|double|const double \*|void \*)\s*\*?(\w+);", body)
     assert fields == [f[0] for f in _lib.Config._fields_]
-    assert ctypes.sizeof(_lib.Config) == 14 * 4 + 3 * 8 + 10 * 8
+    assert ctypes.sizeof(_lib.Config) == 16 * 4 + 3 * 8 + 10 * 8      # 15 int32 + 4 bytes padding
 
 
 def test_no_cpu_fallback_without_device():

@@ -272,3 +272,79 @@ def test_full_size_properties_c4(g):
     assert np.all(vn[:, -1, :] == 0.0)
     assert all(np.isfinite(x).all() for x in (pn, un, vn, tn, qn))
     assert np.max(np.abs(un - u)) > 1e-6                    # it did move
+
+
+def test_fp32_tolerance_sweep(g):
+    """BASELINE configs[4] names an fp32 vs fp64 tolerance sweep: the fp32 handle (arithmetic and
+    storage in float, host API float64) against the fp64 one after 1 / 10 / 100 steps.  fp32 has
+    ~1.2e-7 resolution on fields of magnitude 1e5 (p) and 3e2 (theta); the winds are O(1)."""
+    from gcmiipy_amd import geometry
+    d = golden("g8_pe25d")
+    geom = geometry.gen_geometry(24, 36, 9, sig_func=geometry.manabe_sig)
+    ic = [d["dense_%s0" % k] for k in "puvtq"]
+    c64 = g.Core(g._lib.PE25D, 36, 24, 9, geom=geom)
+    c32 = g.Core(g._lib.PE25D, 36, 24, 9, geom=geom, dtype="f32")
+    c64.set_state(*ic)
+    c32.set_state(*ic)
+    done, errs = 0, {}
+    for n in (1, 10, 100):
+        c64.step(n - done, 30.0)
+        c32.step(n - done, 30.0)
+        done = n
+        a, b = c32.get_state(), c64.get_state()
+        errs[n] = [rel_err(x, y) for x, y in zip(a, b)]
+        assert all(np.isfinite(x).all() for x in a)
+    c64.close()
+    c32.close()
+    assert max(errs[1]) < 2e-6, errs                      # one step: rounding of the state itself
+    assert max(errs[1][0], errs[1][3]) < 2e-7, errs        # p and theta to fp32 resolution
+    assert max(errs[100]) < 5e-2, errs                     # error growth stays bounded over 100 steps
+    assert errs[100][0] < 1e-5 and errs[100][3] < 1e-5, errs
+    # vs the golden (reference) fp64 values after 10 steps the fp32 run is within its own resolution
+    print("fp32 vs fp64 relative error (p,u,v,t,q):", {k: ["%.1e" % e for e in v] for k, v in errs.items()})
+
+
+def test_fp32_bands_in_process(g):
+    import torch
+    from gcmiipy_amd import geometry
+    from gcmiipy_amd.bands import split_rows
+    H, W, L, steps, nb = 14, 20, 5, 2, 2
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    rng = np.random.default_rng(3)
+    p = 1e5 + 10 * rng.standard_normal((H, W))
+    u, v = rng.standard_normal((L, H, W)), rng.standard_normal((L, H, W))
+    v[:, -1, :] = 0
+    t = (300 + rng.standard_normal((L, H, W))) * ((1e5 / (p * geom.sig + geom.ptop)) ** (287.0 / 1004.0))
+    q = 3e-6 * (1 + 0.1 * rng.random((L, H, W)))
+    ref = g.Core(g._lib.PE25D, W, H, L, geom=geom, dtype="f32")
+    ref.set_state(p, u, v, t, q)
+    ref.step(steps, 120.0)
+    want = ref.get_state()
+    ref.close()
+    cores = []
+    for r, (row0, n) in enumerate(split_rows(H, nb)):
+        c = g.Core(g._lib.PE25D, W, n, L, geom=geom, nranks=nb, rank=r, global_height=H, row0=row0, dtype="f32")
+        sl = slice(row0, row0 + n)
+        c.set_state(p[sl], u[:, sl], v[:, sl], t[:, sl], q[:, sl])
+        cores.append(c)
+    def exchange():
+        bufs = [[torch.empty(c.halo_bytes(), dtype=torch.uint8, device="cuda") for _ in (0, 1)] for c in cores]
+        for r, c in enumerate(cores):
+            c.halo_pack(0, bufs[r][0].data_ptr()); c.halo_pack(1, bufs[r][1].data_ptr())
+        torch.cuda.synchronize()
+        for r, c in enumerate(cores):
+            c.halo_unpack(1, bufs[(r + 1) % nb][0].data_ptr()); c.halo_unpack(0, bufs[(r - 1) % nb][1].data_ptr())
+        torch.cuda.synchronize()
+    for _ in range(steps):
+        exchange()
+        for c in cores:
+            c.step_interior(120.0)
+        exchange()
+        for c in cores:
+            c.step_boundary(120.0)
+    parts = [c.get_state() for c in cores]
+    for c in cores:
+        c.close()
+    for f in range(5):
+        got = np.concatenate([p_[f] for p_ in parts], axis=0 if f == 0 else 1)
+        assert np.array_equal(got, want[f]), f             # same fp32 arithmetic per row: bit-identical
