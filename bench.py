@@ -152,8 +152,7 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
                 else:
                     core.step(n, dt)
             else:
-                for _ in range(n):
-                    runner.step(dt)
+                runner.run(n, dt)
     else:
         def run(n, timed=False):
             pass

@@ -193,8 +193,8 @@ def _worker(rank, world, port, model, outdir):
                    stream=torch.cuda.current_stream().cuda_stream)
         c.set_state(ic[0][sl], *[a[:, sl] for a in ic[1:]])
     runner = BandRunner(HipBandEngine(c, torch, stream_aware=False), rank, world, dist)
-    for _ in range(steps):
-        runner.step(dt)
+    runner.run(1, dt)                 # chunked path: a partial window first, then the rest
+    runner.run(steps - 1, dt)
     torch.cuda.synchronize()
     st = c.get_state()
     np.savez(os.path.join(outdir, "r%d.npz" % rank), **{k: a for k, a in zip("puvtq", st) if a is not None})
@@ -203,12 +203,13 @@ def _worker(rank, world, port, model, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model", ["c3", "c3deep", "pe"])
-def test_band_runner_two_processes_one_gpu(tmp_path, model):
+@pytest.mark.parametrize("model,world", [("c3", 2), ("c3deep", 2), ("pe", 2), ("c3deep", 4), ("pe", 4)])
+def test_band_runner_processes_one_gpu(tmp_path, model, world):
+    """world = 4: every rank has two distinct ring neighbours (the N = 2 ring talks to one peer
+    twice); four processes share the GPU (the box allows six)"""
     import torch.multiprocessing as mp
     import gcmiipy_amd as g
     from gcmiipy_amd import geometry
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), model, str(tmp_path)), nprocs=world, join=True)
     parts = [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(world)]
     if model in ("c3", "c3deep"):
