@@ -64,6 +64,7 @@ SYMBOLS = {
     "gcm_halo_unpack": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
     "gcm_step_interior": (C.c_int, [_H, C.c_double, C.c_void_p]),
     "gcm_step_boundary": (C.c_int, [_H, C.c_double, C.c_void_p]),
+    "gcm_step_phase": (C.c_int, [_H, C.c_int, C.c_double, C.c_void_p]),
     "gcm_sync": (C.c_int, [_H]),
     "gcm_advect2d": (C.c_int, [C.c_int] * 6 + [C.c_double] * 3 + [C.c_void_p] * 3),
     "gcm_pgf2d": (C.c_int, [C.c_int] * 3 + [C.c_double] * 3 + [C.c_void_p] * 3),

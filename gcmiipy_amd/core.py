@@ -205,6 +205,9 @@ class Core:
     def step_boundary(self, dt, stream=None):
         _check(lib.gcm_step_boundary(self._h, float(dt), stream), self._h)
 
+    def step_phase(self, phase, dt, stream=None):
+        _check(lib.gcm_step_phase(self._h, int(phase), float(dt), stream), self._h)
+
     def close(self):
         if getattr(self, "_h", None):
             lib.gcm_destroy(self._h)

@@ -457,6 +457,12 @@ int gcm_step_boundary(gcm_handle *h, double dt, void *stream) {
     return GCM_OK;
 }
 
+int gcm_step_phase(gcm_handle *h, int phase, double dt, void *stream) {
+    if (!h) return GCM_ERR_ARG;
+    if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_step_phase: GCM_PE25D latitude bands only");
+    return pe25d_step_phase(h->pe, phase, dt, (hipStream_t)stream, &h->err);
+}
+
 int gcm_half_step(gcm_handle *h, int stage, double dt) {
     if (!h || (stage != 0 && stage != 1)) return GCM_ERR_ARG;
     if (h->pe) return pe25d_half(h->pe, stage, dt, h->stream, &h->err);

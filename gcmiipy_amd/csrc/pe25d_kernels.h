@@ -20,6 +20,7 @@ int pe25d_get(Pe25d *m, bool star, double *p, double *u, double *v, double *t, d
               std::string *err);
 int pe25d_step(Pe25d *m, double dt, hipStream_t s, std::string *err);
 int pe25d_step_part(Pe25d *m, int part, double dt, hipStream_t s, std::string *err);
+int pe25d_step_phase(Pe25d *m, int phase, double dt, hipStream_t s, std::string *err);
 int pe25d_half(Pe25d *m, int stage, double dt, hipStream_t s, std::string *err);
 size_t pe25d_halo_bytes(const Pe25d *m);
 int pe25d_halo(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s, std::string *err);

@@ -791,6 +791,7 @@ struct Pe25d {
     PeBufs<float> f;
     int cur_i = 0;
     bool star_valid = false;
+    int pack_set = -1;                          // >= 0: state set gcm_halo_pack reads (step_phase)
     double *stage3 = nullptr;                   // float64 transpose staging, host layout
     double *exner_tab = nullptr;
     FftPlan plan{};
@@ -1064,36 +1065,54 @@ static void tick(Pe25d *m, hipStream_t s) {
     if (m->ev && m->ev_used && *m->ev_used < m->ev->size()) (void)hipEventRecord((*m->ev)[(*m->ev_used)++], s);
 }
 
-// one Euler stage over rows [j0, j1): state `stage_set` -> `out_set`, base = current
+// one Euler stage over rows [j0, j1): state `stage_set` -> `out_set`, base = current.
+// mode 0: everything; mode 1: K1-K3 on all rows + K4 on the two edge rows of either side (the rows
+// a neighbouring band needs); mode 2: K4 on the remaining interior rows.  Modes 1 + 2 == mode 0.
 template <typename T>
-static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1, hipStream_t s) {
+static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1, hipStream_t s, int mode) {
     if (j1 <= j0) return;
     PeArgsT<T> a = make_args<T>(m, stage_set, out_set, dt);
     const int W = m->W, L = m->L;
     const int ext = m->wrap ? 0 : 1;             // intermediates are also needed on row j1 (south)
     const size_t lds = (size_t)(m->plan.inplace ? 1 : 2) * W * sizeof(typename Vec2<T>::type);
     const int pairs = (L + 1) / 2;
-    a.j0 = j0;
-    a.j1 = j1 + ext;
-    hipLaunchKernelGGL(pe_spu_filter_kernel<T>, dim3(a.j1 - a.j0, pairs), dim3(kFftThreads), lds, s, a);
-    {
-        const long tiles = (long)((W + kColThreads - 1) / kColThreads) * (a.j1 - a.j0);
-        hipLaunchKernelGGL(pe_column_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kColThreads),
-                           sizeof(T) * (size_t)L * kColThreads, s, a);
+    if (mode != 2) {
+        a.j0 = j0;
+        a.j1 = j1 + ext;
+        hipLaunchKernelGGL(pe_spu_filter_kernel<T>, dim3(a.j1 - a.j0, pairs), dim3(kFftThreads), lds, s, a);
+        {
+            const long tiles = (long)((W + kColThreads - 1) / kColThreads) * (a.j1 - a.j0);
+            hipLaunchKernelGGL(pe_column_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kColThreads),
+                               sizeof(T) * (size_t)L * kColThreads, s, a);
+        }
+        a.j1 = j1;
+        hipLaunchKernelGGL(pe_pgf_filter_kernel<T>, dim3(a.j1 - a.j0, pairs), dim3(kFftThreads), lds, s, a);
     }
-    a.j1 = j1;
-    hipLaunchKernelGGL(pe_pgf_filter_kernel<T>, dim3(a.j1 - a.j0, pairs), dim3(kFftThreads), lds, s, a);
-    tick(m, s);
-    {
-        const long tiles = (long)((W + 255) / 256) * (a.j1 - a.j0);
+    auto update_rows = [&](int r0, int r1) {
+        if (r1 <= r0) return;
+        a.j0 = r0;
+        a.j1 = r1;
+        const long tiles = (long)((W + 255) / 256) * (r1 - r0);
         hipLaunchKernelGGL(pe_update_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, s, a);
+    };
+    const bool split = mode != 0 && (j1 - j0) > 2 * kGhost;
+    if (mode == 0 || !split) {
+        if (mode != 2) {      // an unsplittable (tiny) band does all of K4 in mode 1
+            tick(m, s);
+            update_rows(j0, j1);
+            tick(m, s);
+        }
+    } else if (mode == 1) {
+        update_rows(j0, j0 + kGhost);
+        update_rows(j1 - kGhost, j1);
+    } else {
+        update_rows(j0 + kGhost, j1 - kGhost);
     }
-    tick(m, s);
 }
 
-static void half(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1, hipStream_t s) {
-    if (m->f32) half_t<float>(m, stage_set, out_set, dt, j0, j1, s);
-    else half_t<double>(m, stage_set, out_set, dt, j0, j1, s);
+static void half(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1, hipStream_t s, int mode = 0) {
+    if (m->f32) half_t<float>(m, stage_set, out_set, dt, j0, j1, s, mode);
+    else half_t<double>(m, stage_set, out_set, dt, j0, j1, s, mode);
 }
 
 int pe25d_half(Pe25d *m, int stage, double dt, hipStream_t s, std::string *err) {
@@ -1158,6 +1177,48 @@ int pe25d_step_part(Pe25d *m, int part, double dt, hipStream_t s, std::string *e
     return GCM_OK;
 }
 
+// Latitude band with the exchange hidden behind the interior rows of K4 (gcm_step_phase):
+//   phase 0  predictor K1-K3 + K4 edge rows   -> the predicted edge rows can be sent
+//   phase 1  predictor K4 interior rows
+//   phase 2  corrector K1-K3 + K4 edge rows   -> the new state's edge rows can be sent
+//   phase 3  corrector K4 interior rows, then the swap
+// gcm_halo_pack after phase 0 / 2 packs the rows just produced; gcm_halo_unpack after phase 1 / 3
+// fills the ghost rows of the predicted / the new current state.
+int pe25d_step_phase(Pe25d *m, int phase, double dt, hipStream_t s, std::string *err) {
+    if (m->wrap) {
+        *err = "step_phase: handle is not a latitude band";
+        return GCM_ERR_STATE;
+    }
+    switch (phase) {
+        case 0:
+            half(m, m->cur_i, 2, dt, 0, m->H, s, 1);
+            m->star_valid = true;
+            m->pack_set = 2;
+            break;
+        case 1:
+            half(m, m->cur_i, 2, dt, 0, m->H, s, 2);
+            break;
+        case 2:
+            half(m, 2, 1 - m->cur_i, dt, 0, m->H, s, 1);
+            m->pack_set = 1 - m->cur_i;
+            break;
+        case 3:
+            half(m, 2, 1 - m->cur_i, dt, 0, m->H, s, 2);
+            m->cur_i = 1 - m->cur_i;
+            m->star_valid = false;
+            m->pack_set = -1;
+            break;
+        default:
+            *err = "step_phase: phase must be 0..3";
+            return GCM_ERR_ARG;
+    }
+    if (hipGetLastError() != hipSuccess) {
+        *err = "hip: pe25d kernel launch failed";
+        return GCM_ERR_HIP;
+    }
+    return GCM_OK;
+}
+
 // ghost rows: [p: 2 rows][u,v,t,q: 2 rows x L levels]; contiguous in the device layout.
 // Which state is exchanged follows the step phase: the predicted state once it exists.
 size_t pe25d_halo_bytes(const Pe25d *m) {
@@ -1167,7 +1228,11 @@ size_t pe25d_halo_bytes(const Pe25d *m) {
 template <typename T>
 static void halo_t(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s) {
     PeBufs<T> &Bf = bufs<T>(m);
-    const int set = m->star_valid ? 2 : m->cur_i;
+    // unpack: ghosts of the predicted state once it exists, else of the current state;
+    // pack: the same, unless a step_phase call named the set whose edge rows were just produced
+    int set = m->star_valid ? 2 : m->cur_i;
+    if (pack && m->pack_set >= 0) set = m->pack_set;
+    if (!pack && m->pack_set >= 0 && m->pack_set != 2) set = m->pack_set;   // new-state ghosts arrive before the swap
     T *b = (T *)dev_buf;
     SegCopy c{};
     for (int f = 0; f < GCM_NFIELDS; ++f) {

@@ -188,6 +188,15 @@ int gcm_halo_unpack(gcm_handle *h, int side, const void *dev_buf, void *stream);
 /* Step split for comm/compute overlap: rows that need no ghost data, then the rest. */
 int gcm_step_interior(gcm_handle *h, double dt, void *stream);
 int gcm_step_boundary(gcm_handle *h, double dt, void *stream);
+/* GCM_PE25D bands, exchange hidden behind the update kernel's interior rows: each Euler stage is
+ * split into "everything the neighbours wait for" and "the rest".  phase 0: predictor K1-K3 + the
+ * update of the two edge rows on either side; gcm_halo_pack then packs the PREDICTED edge rows;
+ * phase 1: predictor update of the interior rows (overlaps the exchange); gcm_halo_unpack fills the
+ * predicted state's ghosts; phase 2 / 3: the same for the corrector (pack = the NEW state's edge
+ * rows; phase 3 ends with the swap; unpack then fills the new current state's ghosts, which the
+ * next step's phase 0 needs).  Before the first step the current state's ghosts must be exchanged
+ * once (pack / unpack with no phase pending).                                                    */
+int gcm_step_phase(gcm_handle *h, int phase, double dt, void *stream);
 
 int gcm_sync(gcm_handle *h);
 

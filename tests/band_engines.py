@@ -102,7 +102,9 @@ class NumpyBandPE:
     current one before the predictor and the predicted one before the corrector."""
     phases = 2
 
-    def __init__(self, p, u, v, t, q, global_geom, row0):
+    def __init__(self, p, u, v, t, q, global_geom, row0, edge_first=False):
+        self.edge_first = edge_first
+        self.pending = None
         self.H = p.shape[0]
         self.row0, self.Hg = row0, global_geom.height
         self.geom = band_geom(global_geom, row0, self.H)
@@ -113,7 +115,28 @@ class NumpyBandPE:
         self.rb = [None, None]
 
     def _xstate(self):
+        if self.pending is not None:
+            return self.pending
         return self.star if self.star is not None else self.cur
+
+    # edge-first protocol (HipBandEngine.compute_edges / compute_interior): the whole stage is
+    # computed in `compute_edges`; what matters here is WHICH state the runner exchanges and
+    # when its ghosts are written
+    def compute_edges(self, stage, dt):
+        if stage == 0:
+            self.star = self._half(self.cur, dt)
+        else:
+            self.pending = self._half(self.star, dt)
+
+    def compute_interior(self, stage, dt):
+        if stage == 1:
+            for a, b in zip(self.cur, self.pending):
+                if a.ndim == 2:
+                    a[G:self.H + G] = b[G:self.H + G]
+                else:
+                    a[:, G:self.H + G] = b[:, G:self.H + G]
+            self.star = None
+            self.pending = None
 
     @staticmethod
     def _rows(a, rows):

@@ -59,7 +59,7 @@ def _worker_2d(rank, world, port, shape, temp, steps, outdir, halo_steps=1):
     dist.destroy_process_group()
 
 
-def _worker_pe(rank, world, port, hwl, steps, outdir):
+def _worker_pe(rank, world, port, hwl, steps, outdir, edge_first=False):
     from band_engines import NumpyBandPE
     from gcmiipy_amd.bands import BandRunner, split_rows
     from oracle import geometry as ogeo
@@ -71,7 +71,7 @@ def _worker_pe(rank, world, port, hwl, steps, outdir):
     p, u, v, t, q = _ic_pe(geom)
     row0, n = split_rows(H, world)[rank]
     sl = slice(row0, row0 + n)
-    eng = NumpyBandPE(p[sl], u[:, sl], v[:, sl], t[:, sl], q[:, sl], geom, row0)
+    eng = NumpyBandPE(p[sl], u[:, sl], v[:, sl], t[:, sl], q[:, sl], geom, row0, edge_first)
     runner = BandRunner(eng, rank, world, dist)
     for _ in range(steps):
         runner.step(120.0)
@@ -138,11 +138,13 @@ def test_banded_2d_deep_halo(tmp_path):
         assert np.array_equal(np.concatenate([pp[k] for pp in parts], axis=0), f[k]), k
 
 
+@pytest.mark.parametrize("edge_first", [False, True])
 @pytest.mark.parametrize("world", [2, 3])
-def test_banded_pe25d_equals_single_domain(tmp_path, world):
+def test_banded_pe25d_equals_single_domain(tmp_path, world, edge_first):
     from oracle import dynamics, geometry as ogeo
     hwl, steps = (12, 16, 3), 2
-    mp.spawn(_worker_pe, args=(world, _free_port(), hwl, steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_pe, args=(world, _free_port(), hwl, steps, str(tmp_path), edge_first), nprocs=world,
+             join=True)
     H, W, L = hwl
     geom = ogeo.gen_geometry(H, W, L, sig_func=ogeo.manabe_sig)
     geom.heightmap[H // 2, 3] = 300.0

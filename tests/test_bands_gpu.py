@@ -155,6 +155,52 @@ def test_bands_in_process_pe25d(nb):
         assert rel_err(got, want[f]) < 1e-13, (k, rel_err(got, want[f]))
 
 
+@pytest.mark.parametrize("nb", [2, 3])
+def test_bands_in_process_pe25d_edge_first(nb):
+    """gcm_step_phase: edge rows first, ghost exchange, interior rows -- same numbers as one band"""
+    import torch
+    import gcmiipy_amd as g
+    from gcmiipy_amd import geometry
+    from gcmiipy_amd.bands import split_rows
+    H, W, L, steps = 15, 20, 5, 3
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    ic = _ic_pe(geom)
+    ref = g.Core(g._lib.PE25D, W, H, L, geom=geom)
+    ref.set_state(*ic)
+    ref.step(steps, 120.0)
+    want = ref.get_state()
+    ref.close()
+    cores = []
+    for r, (row0, n) in enumerate(split_rows(H, nb)):
+        c = g.Core(g._lib.PE25D, W, n, L, geom=geom, nranks=nb, rank=r, global_height=H, row0=row0)
+        sl = slice(row0, row0 + n)
+        c.set_state(ic[0][sl], *[a[:, sl] for a in ic[1:]])
+        cores.append(c)
+    _exchange(cores, torch)                  # ghosts of the initial state
+    for _ in range(steps):
+        for stage in (0, 1):
+            for c in cores:
+                c.step_phase(2 * stage, 120.0)
+            bufs = [[torch.empty(c.halo_bytes() // 8, dtype=torch.float64, device="cuda") for _ in (0, 1)]
+                    for c in cores]
+            for r, c in enumerate(cores):        # pack BEFORE the interior phase, as the runner does
+                c.halo_pack(0, bufs[r][0].data_ptr())
+                c.halo_pack(1, bufs[r][1].data_ptr())
+            for c in cores:
+                c.step_phase(2 * stage + 1, 120.0)
+            torch.cuda.synchronize()
+            for r, c in enumerate(cores):
+                c.halo_unpack(1, bufs[(r + 1) % nb][0].data_ptr())
+                c.halo_unpack(0, bufs[(r - 1) % nb][1].data_ptr())
+            torch.cuda.synchronize()
+    parts = [c.get_state() for c in cores]
+    for c in cores:
+        c.close()
+    for f, k in enumerate("puvtq"):
+        got = np.concatenate([p_[f] for p_ in parts], axis=0 if f == 0 else 1)
+        assert rel_err(got, want[f]) < 1e-13, (k, rel_err(got, want[f]))
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
