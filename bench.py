@@ -38,7 +38,14 @@ WORKLOADS = {
     # the same workload with arithmetic and storage in fp32 (BASELINE configs[4]: fp32 vs fp64 sweep)
     "c4_f32": ("2.5-D sigma-level primitive equations, 1440x720x24 fp32",
                720, 1440, 24, "PE25D", None, 32.0 + 8.0 / 24, 1.0),
+    # BASELINE configs[4] grid (dynamics only; the radiation + fp32-vs-fp64 sweep is tools/tools_c5_sweep.py);
+    # not part of the default run: --workload c5 / c5_f32
+    "c5": ("2.5-D sigma-level primitive equations, 2880x1440x40 fp64 (BASELINE configs[4] grid)",
+           1440, 2880, 40, "PE25D", None, 64.0 + 16.0 / 40, 1.0),
+    "c5_f32": ("2.5-D sigma-level primitive equations, 2880x1440x40 fp32 (BASELINE configs[4] grid)",
+               1440, 2880, 40, "PE25D", None, 32.0 + 8.0 / 40, 1.0),
 }
+ALSO = ("c2", "c3", "c4", "c4_f32")     # secondary workloads of the default run
 DX = 300e3
 
 
@@ -47,7 +54,7 @@ def synth(name, H, W, L=1, row0=0, nrows=None, geom=None):
     rng = np.random.default_rng(0)
     nrows = H if nrows is None else nrows
     sl = slice(row0, row0 + nrows)
-    if name.startswith("c4"):
+    if WORKLOADS[name][4] == "PE25D":
         p = 1e5 + 10 * rng.standard_normal((H, W))
         u = rng.standard_normal((L, H, W))
         v = rng.standard_normal((L, H, W))
@@ -72,7 +79,7 @@ def cpu_baseline(name):
     """the oracle (NumPy restatement, bit-identical to the reference) on the host, 1 core"""
     from oracle import sw2d, sw2d_temp, tracer
     _, H, W, L, _, _, _, dt = WORKLOADS[name]
-    if name.startswith("c4"):
+    if WORKLOADS[name][4] == "PE25D":
         # bounded sample: the same recipe on a 360x180x24 grid (1/16 of the cells), 2 steps
         from oracle import dynamics, geometry as ogeo
         h, w = 180, 360
@@ -80,12 +87,13 @@ def cpu_baseline(name):
         s = synth(name, h, w, L, geom=og)
         st = (s["p"], s["u"], s["v"], s["t"], s["q"])
         t0 = time.perf_counter()
-        for _ in range(2):
+        nst = 12
+        for _ in range(nst):
             st = dynamics.matsuno_timestep(*st, dt, og)
         el = time.perf_counter() - t0
-        return {"value": h * w * L * 2 / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
-                "sample": "2 steps of a 360x180x24 grid (1/16 of the cells, same recipe) with the NumPy "
-                          "oracle, %.1f s; host has %d cores" % (el, os.cpu_count())}
+        return {"value": h * w * L * nst / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+                "sample": "%d steps of a 360x180x%d grid (same recipe, fewer columns) with the NumPy "
+                          "oracle, %.1f s; host has %d cores" % (nst, L, el, os.cpu_count())}
     s = synth(name, H, W)
     t0 = time.perf_counter()
     if name == "c2":
@@ -260,7 +268,7 @@ def main():
     main_res = run_workload(cx, a.workload, a.steps, a.warmup, a.variant)
     also = {}
     if not a.only:
-        for name in sorted(WORKLOADS):
+        for name in ALSO:
             if name == a.workload:
                 continue
             if cx.world > 1 and name == "c2":

@@ -29,7 +29,7 @@ struct FftPlan {
     int n, nrad;
     int rad[kMaxRadices];
     unsigned magic[kMaxRadices];   // ceil(2^32 / Ns) per pass: b / Ns == umulhi(b, magic) for b*Ns < 2^32
-    int inplace;                   // 1: only radices 2,3,4,5 and N/2 <= kMaxBfly*256: single-buffer passes
+    int inplace;                   // 1: only radices 2,3,4,5 and N/r <= kMaxBfly*kFftThreads: single-buffer passes
 };
 
 template <typename T> struct Vec2;
@@ -190,7 +190,7 @@ __device__ V *fft_lds(V *x, V *y, const V *tw, const FftPlan &P) {
 // most kMaxBfly) butterflies into registers, the workgroup synchronises, and the outputs go back
 // into the SAME buffer.  Half the LDS of the ping-pong form, so twice the workgroups per CU.
 constexpr int kFftThreads = 512;
-constexpr int kMaxBfly = 2;    // ceil((N / 2) / kFftThreads) for N <= 1536
+constexpr int kMaxBfly = 2;    // butterflies per thread and pass (make_plan checks N / r against it)
 
 template <int R, bool INV, typename V>
 __device__ __forceinline__ void butterfly(V (&v)[R]) {
@@ -681,17 +681,21 @@ __global__ __launch_bounds__(256) void pe_energy_kernel(PeArgs a, const double *
 // ---------------------------------------------------------------- grey radiation (column physics)
 // basic_grey_radiation (grey_solar.py:358-563) + solar_timestep (no_limits_2_5d.py:66-75):
 // one thread per (j,i) column, the upwelling scan bottom-up, the downwelling scan top-down.
-struct RadArgs {
+template <typename T>
+struct RadArgsT {
     const double *tlw, *tsw, *csw_top, *clw_b_div, *swfac;   // [L] level tables (host-built)
     const double *coslat, *sinlat, *lon;                     // [Hg], [Hg], [W]
     double *gt;                                              // ground temperature [H][W]
-    double *emis, *lwb, *ttp;                                // 3-D scratch (parked per level)
-    double *dTdt, *dtg;                                      // tendencies out (3-D, 2-D scratch)
+    T *emis, *lwb, *ttp;                                     // 3-D scratch (parked per level)
+    T *dTdt, *dtg;                                           // tendencies out (3-D, 2-D scratch)
     double hour_angle, albedo, dt;
     int apply;                                               // 1: t, gt updated in place
 };
 
-__global__ __launch_bounds__(256) void pe_radiation_kernel(PeArgs a, RadArgs r, double *t_inout) {
+// The arithmetic is float64 for either storage type T: the column physics is a small share of a
+// step, and the fp32 variant then differs from fp64 only by the rounding of what it stores.
+template <typename T>
+__global__ __launch_bounds__(256) void pe_radiation_kernel(PeArgsT<T> a, RadArgsT<T> r, T *t_inout) {
     __shared__ double tab[kExnerTabDoubles];
     tab[threadIdx.x] = a.exner_tab[threadIdx.x];
     __syncthreads();
@@ -702,7 +706,7 @@ __global__ __launch_bounds__(256) void pe_radiation_kernel(PeArgs a, RadArgs r, 
     if (i >= W) return;
     const int jg = wrapi(a.row0 + j, a.Hg);
     const long c3 = (long)j * L * W + i, c2 = (long)j * W + i;
-    const double pc = a.p[c2], gt = r.gt[c2];
+    const double pc = (double)a.p[c2], gt = r.gt[c2], ptop = (double)a.ptop;
     // zenith_angle, grey_solar.py:49-65 (declination 0)
     const double pa = r.lon[i] + r.hour_angle;
     const double sza = fmax(r.sinlat[jg] * 0.0 + r.coslat[jg] * 1.0 * cos(pa), 0.0);
@@ -713,33 +717,33 @@ __global__ __launch_bounds__(256) void pe_radiation_kernel(PeArgs a, RadArgs r, 
     double B = 0.0, up = 0.0;
     for (int k = 0; k < L; ++k) {                            // bottom-up: emission, B, LWA_b
         const long o = c3 + (long)k * W;
-        const double tp = pc * a.sig[k] + a.ptop;
-        const double tt = t_inout[o] * exner(tp, tab);       // to_true_temp
+        const double tp = pc * (double)a.sig[k] + ptop;
+        const double tt = (double)t_inout[o] * exner(tp, tab);       // to_true_temp
         const double t2 = tt * tt;
         const double em = (1 - r.tlw[k]) * kSb * (t2 * t2);
         B += em * r.clw_b_div[k];
-        r.lwb[o] = up * (1 - r.tlw[k]);
+        r.lwb[o] = (T)(up * (1 - r.tlw[k]));
         up = up * r.tlw[k] + em;
-        r.emis[o] = em;
-        r.ttp[o] = tt;
+        r.emis[o] = (T)em;
+        r.ttp[o] = (T)tt;
     }
     const double dtg = (B + S - U_s) / kCg / (.1);
-    r.dtg[c2] = dtg;
+    r.dtg[c2] = (T)dtg;
     if (r.apply) r.gt[c2] = gt + dtg * r.dt;
     double down = 0.0;
     for (int k = L - 1; k >= 0; --k) {                       // top-down: LWA_a, then eq. 2.34
         const long o = c3 + (long)k * W;
-        const double em = r.emis[o];
+        const double em = (double)r.emis[o];
         const double lwa = down * (1 - r.tlw[k]);
         down = down * r.tlw[k] + em;
         const double U_n = r.clw_b_div[k] * U_s * (1 - r.tlw[k]);
         const double S_n = r.swfac[k] * Sc;
-        const double dTdt = (U_n + S_n - 2 * em + lwa + r.lwb[o]) * (kG / (kCp * pc * a.dsig[k]));
-        r.dTdt[o] = dTdt;
+        const double dTdt = (U_n + S_n - 2 * em + lwa + (double)r.lwb[o]) * (kG / (kCp * pc * (double)a.dsig[k]));
+        r.dTdt[o] = (T)dTdt;
         if (r.apply) {
-            const double tp = pc * a.sig[k] + a.ptop;
-            const double tt_n = r.ttp[o] + dTdt * r.dt;
-            t_inout[o] = tt_n * rcp(exner(tp, tab));          // to_potential_temp
+            const double tp = pc * (double)a.sig[k] + ptop;
+            const double tt_n = (double)r.ttp[o] + dTdt * r.dt;
+            t_inout[o] = (T)(tt_n * rcp(exner(tp, tab)));          // to_potential_temp
         }
     }
 }
@@ -787,6 +791,7 @@ struct Pe25d {
     int W = 0, H = 0, L = 0, Hg = 0;
     bool wrap = true, f32 = false;
     std::vector<void *> allocs;
+    std::vector<double> dsig_host;              // geometry.py dsig, float64 (radiation level tables)
     PeBufs<double> d;
     PeBufs<float> f;
     int cur_i = 0;
@@ -821,9 +826,11 @@ static bool make_plan(int n, FftPlan *P) {
         P->magic[i] = (unsigned)(((1ULL << 32) + (unsigned long long)Ns - 1) / (unsigned long long)Ns);
         Ns *= P->rad[i];
     }
-    P->inplace = (n / 2 <= kMaxBfly * kFftThreads) ? 1 : 0;
+    // in place when every pass is a {2,3,4,5} butterfly and its n / r butterflies fit the
+    // kMaxBfly register slots of the workgroup (2880 = 4.4.4.3.3.5: at most 960 per pass)
+    P->inplace = 1;
     for (int i = 0; i < P->nrad; ++i)
-        if (P->rad[i] > 5) P->inplace = 0;
+        if (P->rad[i] > 5 || n / P->rad[i] > kMaxBfly * kFftThreads) P->inplace = 0;
     return m == 1 && P->nrad <= kMaxRadices;
 }
 
@@ -949,6 +956,7 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
     m->Hg = cfg.global_height;
     m->wrap = cfg.nranks == 1;
     m->f32 = cfg.dtype == GCM_F32;
+    m->dsig_host.assign(cfg.dsig, cfg.dsig + cfg.layers);
     const int W = m->W, L = m->L;
     auto bad = [&](const char *what) {
         *err = std::string("hip: GCM_PE25D allocation/upload failed: ") + what;
@@ -1282,21 +1290,48 @@ int pe25d_ground(Pe25d *m, bool set, const double *in, double *out, std::string 
     return GCM_OK;
 }
 
+template <typename T>
+static int radiation_launch(Pe25d *m, bool apply, double dt, double hour_angle, double albedo,
+                            double *dTdt_host, double *dtg_host, hipStream_t s, std::string *err) {
+    PeBufs<T> &B = bufs<T>(m);
+    const int W = m->W, H = m->H, L = m->L, Hg = m->Hg;
+    PeArgsT<T> a = make_args<T>(m, m->cur_i, m->cur_i, dt);
+    RadArgsT<T> r{};
+    r.tlw = m->rad_tab; r.tsw = r.tlw + L; r.csw_top = r.tsw + L; r.clw_b_div = r.csw_top + L; r.swfac = r.clw_b_div + L;
+    r.coslat = m->rad_geo; r.sinlat = m->rad_geo + Hg; r.lon = m->rad_geo + 2 * Hg;
+    r.gt = m->gt;
+    r.emis = B.spu; r.lwb = B.phi; r.ttp = B.rho; r.dTdt = B.pgfu; r.dtg = B.pit;
+    r.hour_angle = hour_angle;
+    r.albedo = albedo; r.dt = dt; r.apply = apply ? 1 : 0;
+    hipLaunchKernelGGL(pe_radiation_kernel<T>, dim3((W + 255) / 256, H), dim3(256), 0, s, a, r, B.st[m->cur_i][GCM_T]);
+    if (hipStreamSynchronize(s) != hipSuccess) { *err = "hip: radiation kernel failed"; return GCM_ERR_HIP; }
+    if (dtg_host) {
+        hipLaunchKernelGGL(pe_to_host_kernel<T>, dim3(64), dim3(256), 0, nullptr, m->stage3, B.pit, W, H, 1);
+        if (hipMemcpy(dtg_host, m->stage3, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost) != hipSuccess) {
+            *err = "hip: dt_ground copy-back failed"; return GCM_ERR_HIP;
+        }
+    }
+    if (dTdt_host) {
+        hipLaunchKernelGGL(pe_to_host_kernel<T>, dim3(1024), dim3(256), 0, nullptr, m->stage3, B.pgfu, W, H, L);
+        if (hipMemcpy(dTdt_host, m->stage3, sizeof(double) * (size_t)H * W * L, hipMemcpyDeviceToHost) != hipSuccess) {
+            *err = "hip: dTdt copy-back failed"; return GCM_ERR_HIP;
+        }
+    }
+    return GCM_OK;
+}
+
 // basic_grey_radiation (+ optional in-place solar_timestep).  dTdt_host / dtg_host may be null.
 int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, double t_sw, double albedo,
                     const double *lat, const double *lon, double *dTdt_host, double *dtg_host,
                     hipStream_t s, std::string *err) {
-    if (m->f32) { *err = "radiation: fp64 handles only"; return GCM_ERR_UNSUPPORTED; }
     if (!m->gt) { *err = "radiation: set the ground temperature first (gcm_set_ground)"; return GCM_ERR_STATE; }
     if (!lat || !lon) { *err = "radiation: lat and lon tables are required"; return GCM_ERR_ARG; }
     const int W = m->W, H = m->H, L = m->L, Hg = m->Hg;
     (void)hipDeviceSynchronize();
     if (m->rad_key[0] != t_lw || m->rad_key[1] != t_sw || !m->rad_tab) {
         // level tables, same expression order as grey_solar.py:323-333,377-385,541
-        std::vector<double> T((size_t)5 * L), dsig(L);
-        if (hipMemcpy(dsig.data(), m->d.dsig, sizeof(double) * L, hipMemcpyDeviceToHost) != hipSuccess) {
-            *err = "hip: radiation table read-back failed"; return GCM_ERR_HIP;
-        }
+        std::vector<double> T((size_t)5 * L);
+        const std::vector<double> &dsig = m->dsig_host;
         double *tlw = T.data(), *tsw = tlw + L, *csw = tsw + L, *cdiv = csw + L, *swf = cdiv + L;
         for (int k = 0; k < L; ++k) {
             tlw[k] = 1 - (1 - std::pow(t_lw, dsig[k]));
@@ -1325,26 +1360,9 @@ int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, do
             *err = "hip: radiation geometry upload failed"; return GCM_ERR_HIP;
         }
     }
-    PeArgs a = make_args<double>(m, m->cur_i, m->cur_i, dt);
-    RadArgs r{};
-    r.tlw = m->rad_tab; r.tsw = r.tlw + L; r.csw_top = r.tsw + L; r.clw_b_div = r.csw_top + L; r.swfac = r.clw_b_div + L;
-    r.coslat = m->rad_geo; r.sinlat = m->rad_geo + Hg; r.lon = m->rad_geo + 2 * Hg;
-    r.gt = m->gt;
-    r.emis = m->d.spu; r.lwb = m->d.phi; r.ttp = m->d.rho; r.dTdt = m->d.pgfu; r.dtg = m->d.pit;
-    r.hour_angle = utc / (-24 * 3600.0) * 360 * (M_PI / 180);      // grey_solar.py:51
-    r.albedo = albedo; r.dt = dt; r.apply = apply ? 1 : 0;
-    hipLaunchKernelGGL(pe_radiation_kernel, dim3((W + 255) / 256, H), dim3(256), 0, s, a, r, m->d.st[m->cur_i][GCM_T]);
-    if (hipStreamSynchronize(s) != hipSuccess) { *err = "hip: radiation kernel failed"; return GCM_ERR_HIP; }
-    if (dtg_host && hipMemcpy(dtg_host, m->d.pit, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost) != hipSuccess) {
-        *err = "hip: dt_ground copy-back failed"; return GCM_ERR_HIP;
-    }
-    if (dTdt_host) {
-        hipLaunchKernelGGL(pe_to_host_kernel<double>, dim3(1024), dim3(256), 0, nullptr, m->stage3, m->d.pgfu, W, H, L);
-        if (hipMemcpy(dTdt_host, m->stage3, sizeof(double) * (size_t)H * W * L, hipMemcpyDeviceToHost) != hipSuccess) {
-            *err = "hip: dTdt copy-back failed"; return GCM_ERR_HIP;
-        }
-    }
-    return GCM_OK;
+    const double hour_angle = utc / (-24 * 3600.0) * 360 * (M_PI / 180);      // grey_solar.py:51
+    return m->f32 ? radiation_launch<float>(m, apply, dt, hour_angle, albedo, dTdt_host, dtg_host, s, err)
+                  : radiation_launch<double>(m, apply, dt, hour_angle, albedo, dTdt_host, dtg_host, s, err);
 }
 
 int pe25d_energy(Pe25d *m, const double *area_host, int area_len, double out[4], std::string *err) {

@@ -114,9 +114,12 @@ def test_geography_harness_h1(g):
     c.close()
 
 
-@pytest.mark.parametrize("hwl", [(8, 16, 4), (6, 10, 3), (5, 12, 1), (12, 20, 5), (7, 30, 2)])
+@pytest.mark.parametrize("hwl", [(8, 16, 4), (6, 10, 3), (5, 12, 1), (12, 20, 5), (7, 30, 2),
+                                 (3, 1440, 2), (4, 2880, 3), (3, 14, 2), (2, 2250, 1)])
 def test_shapes_vs_oracle(g, hwl):
-    """ragged sizes: odd L (unpaired level in the packed FFT), radix-3/5 widths, L = 1"""
+    """ragged sizes: odd L (unpaired level in the packed FFT), radix-3/5 widths, L = 1; the row
+    lengths of BASELINE configs[3] / [4] (1440, 2880: in-place FFT), a radix-7 length (generic
+    butterfly, ping-pong buffers) and 2250 = 2.3.3.5.5.5, whose radix-2 pass is too wide for the in-place form"""
     from gcmiipy_amd import geometry
     from oracle import dynamics as odyn, geometry as ogeo, temperature as otemp
     H, W, L = hwl
@@ -245,6 +248,28 @@ def test_grey_radiation_and_solar_timestep(g):
         t_n, g_n = grey_solar.solar_timestep(t, p, gv, float(d["dt"]), utc, geom)
         assert rel_err(t_n, d["t_n_" + tag]) < TOL
         assert rel_err(g_n.gt, d["gt_n_" + tag]) < TOL
+
+
+def test_grey_radiation_fp32_handle(g):
+    """the column physics on a float32 handle (float64 arithmetic, float32 storage) against the
+    float64 handle: tendencies and the stepped theta to float32 resolution"""
+    from gcmiipy_amd import geometry
+    d = golden("g13_radiation")
+    L, H, W = d["t0"].shape
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    z = np.zeros((L, H, W))
+    res = {}
+    for dt_name in ("f64", "f32"):
+        c = g.Core(g._lib.PE25D, W, H, L, geom=geom, dtype=dt_name)
+        c.set_state(d["p0"], z, z, d["t0"], z)
+        c.set_ground(d["gt0"])
+        dTdt, dtg = c.grey_radiation(geom, float(d["utc_a"]))
+        c.solar_step(geom, float(d["dt"]), float(d["utc_a"]))
+        res[dt_name] = (dTdt, dtg, c.get_state()[3], c.get_ground())
+        c.close()
+    assert rel_err(res["f64"][0], d["dTdt_a"]) < TOL and rel_err(res["f64"][2], d["t_n_a"]) < TOL
+    for a, b, tol in zip(res["f32"], res["f64"], (2e-5, 2e-5, 3e-7, 1e-7)):
+        assert rel_err(a, b) < tol, (rel_err(a, b), tol)
 
 
 def test_full_size_properties_c4(g):
