@@ -15,6 +15,7 @@
 // it acts on both parts independently), multiplied by S[j][n] and transformed back.
 #include "pe25d_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -29,7 +30,14 @@ struct FftPlan {
     int n, nrad;
     int rad[kMaxRadices];
     unsigned magic[kMaxRadices];   // ceil(2^32 / Ns) per pass: b / Ns == umulhi(b, magic) for b*Ns < 2^32
-    int inplace;                   // 1: only radices 2,3,4,5 and N/r <= kMaxBfly*kFftThreads: single-buffer passes
+};
+
+constexpr int kMaxSuper = 8;
+struct SuperPlan {
+    int ok;                        // 0: use the generic ping-pong path
+    int npass, threads, maxr;      // workgroup size = widest pass rounded up to whole waves
+    int r1[kMaxSuper], r2[kMaxSuper];
+    unsigned magic[kMaxSuper];     // ceil(2^32 / Ns) of the pass
 };
 
 template <typename T> struct Vec2;
@@ -60,7 +68,8 @@ struct PeArgsT {
     const T *smul;                    // [Hg][W/2+1] filter multiplier (low_pass.py:61-72)
     const T2 *tw;                     // [W] exp(-2 pi i n / W)
     const double *exner_tab;               // always float64 (gcm_math.h exner())
-    FftPlan plan;
+    FftPlan plan;                          // generic ping-pong passes (fallback)
+    SuperPlan cplan;                       // composite-radix in-place passes
     int W, H, L, Hg, row0;                 // local rows, global rows, first global row
     int wrap;                              // 1: rows wrap modulo H (single band)
     int filter;
@@ -186,16 +195,19 @@ __device__ V *fft_lds(V *x, V *y, const V *tw, const FftPlan &P) {
     return x;
 }
 
-// ---- in-place variant for {2,3,4,5}-smooth lengths: every thread pulls the inputs of its (at
-// most kMaxBfly) butterflies into registers, the workgroup synchronises, and the outputs go back
-// into the SAME buffer.  Half the LDS of the ping-pong form, so twice the workgroups per CU.
-constexpr int kFftThreads = 512;
-constexpr int kMaxBfly = 2;    // butterflies per thread and pass (make_plan checks N / r against it)
-
+// ---- composite-radix in-place passes for {2,3,5}-smooth lengths (the product path).
+// A pass has radix R = R1 * R2 (R1, R2 in {2,3,4,5}, R2 may be 1): 1440 = 10.12.12 is three
+// passes per direction instead of six, each thread does ONE R-point butterfly per pass entirely in
+// registers (Cooley-Tukey split into R2 butterflies of radix R1, the W_R twiddles, R1 butterflies
+// of radix R2), and a workgroup has only as many threads as the widest pass has butterflies.
+// The first forward pass reads its inputs straight from global memory (a functor), the first
+// inverse pass applies the filter multiplier while it reads, the last inverse pass stores to
+// global memory: LDS holds one row of complex values and is touched once per pass.
 template <int R, bool INV, typename V>
 __device__ __forceinline__ void butterfly(V (&v)[R]) {
     using T = Sc<V>;
-    if (R == 2) {
+    if (R == 1) {
+    } else if (R == 2) {
         const V a0 = v[0], a1 = v[1];
         v[0] = cadd(a0, a1);
         v[1] = csub(a0, a1);
@@ -232,72 +244,128 @@ __device__ __forceinline__ void butterfly(V (&v)[R]) {
     }
 }
 
-template <int R, bool INV, typename V>
-__device__ __forceinline__ void pass_inplace(V *x, const V *tw, int N, int Ns, unsigned magic) {
+// R-point DFT of v[m], m = R2 m1 + m2, result v[q], q = q1 + R1 q2:
+//   W_R^(m q) = W_R1^(m1 q1) . W_R^(m2 q1) . W_R2^(m2 q2);   W_R^t = tw[t * wstep], wstep = N / R
+template <int R1, int R2, bool INV, typename V>
+__device__ __forceinline__ void dft_composite(V (&v)[R1 * R2], const V *tw, int wstep) {
+    if constexpr (R2 == 1) {
+        butterfly<R1, INV>(v);
+    } else {
+    V a[R1 * R2];                                  // a[q1 R2 + m2]
+#pragma unroll
+    for (int m2 = 0; m2 < R2; ++m2) {
+        V t[R1];
+#pragma unroll
+        for (int m1 = 0; m1 < R1; ++m1) t[m1] = v[R2 * m1 + m2];
+        butterfly<R1, INV>(t);
+#pragma unroll
+        for (int q1 = 0; q1 < R1; ++q1) a[q1 * R2 + m2] = t[q1];
+    }
+#pragma unroll
+    for (int q1 = 1; q1 < R1; ++q1)
+#pragma unroll
+        for (int m2 = 1; m2 < R2; ++m2) a[q1 * R2 + m2] = cmul(a[q1 * R2 + m2], twid<INV>(tw, (m2 * q1) * wstep));
+#pragma unroll
+    for (int q1 = 0; q1 < R1; ++q1) {
+        V t[R2];
+#pragma unroll
+        for (int m2 = 0; m2 < R2; ++m2) t[m2] = a[q1 * R2 + m2];
+        butterfly<R2, INV>(t);
+#pragma unroll
+        for (int q2 = 0; q2 < R2; ++q2) v[q1 + R1 * q2] = t[q2];
+    }
+    }
+}
+
+// one Stockham pass, one butterfly per thread.  src(i) -> V reads element i of the pass input,
+// dst(i, V) writes element i of its output; `fence` = both are the same LDS buffer.
+template <int R1, int R2, bool INV, typename V, typename Src, typename Dst>
+__device__ __forceinline__ void composite_pass(const Src &src, const Dst &dst, bool fence, const V *tw, int N, int Ns,
+                                               unsigned magic) {
+    constexpr int R = R1 * R2;
     const int nb = N / R;
-    const int tstep = N / (Ns * R);
-    V v[kMaxBfly][R];
-    int j0[kMaxBfly];
+    const int b = threadIdx.x;
+    const bool act = b < nb;
+    V v[R];
+    int j0 = 0;
+    if (act) {
+        const int blk = Ns == 1 ? b : (int)__umulhi((unsigned)b, magic);
+        const int k = b - blk * Ns;
+        j0 = blk * Ns * R + k;
 #pragma unroll
-    for (int n = 0; n < kMaxBfly; ++n) {
-        const int b = threadIdx.x + n * blockDim.x;
-        if (b < nb) {
-            const int blk = Ns == 1 ? b : (int)__umulhi((unsigned)b, magic);
-            const int k = b - blk * Ns;
-            j0[n] = blk * Ns * R + k;
-            const int t1 = k * tstep;
-            v[n][0] = x[b];
+        for (int m = 0; m < R; ++m) v[m] = src(b + m * nb);
+        if (Ns > 1) {
+            // pass twiddles w^(m t1): ONE gathered table entry per butterfly (the lanes' indices are
+            // strided, so a gather costs a cache line per lane), the powers by squaring / one product
+            const int t1 = k * (nb / Ns);          // k * N / (Ns R)
+            V wp[R];
+            wp[1] = twid<INV>(tw, t1);
 #pragma unroll
-            for (int m = 1; m < R; ++m) v[n][m] = cmul(x[b + m * nb], twid<INV>(tw, m * t1));
-            butterfly<R, INV>(v[n]);
+            for (int m = 2; m < R; ++m) wp[m] = (m % 2 == 0) ? cmul(wp[m / 2], wp[m / 2]) : cmul(wp[m - 1], wp[1]);
+#pragma unroll
+            for (int m = 1; m < R; ++m) v[m] = cmul(v[m], wp[m]);
         }
+        dft_composite<R1, R2, INV>(v, tw, nb);
     }
-    __syncthreads();
+    if (fence) __syncthreads();
+    if (act) {
 #pragma unroll
-    for (int n = 0; n < kMaxBfly; ++n) {
-        const int b = threadIdx.x + n * blockDim.x;
-        if (b < nb) {
-#pragma unroll
-            for (int q = 0; q < R; ++q) x[j0[n] + q * Ns] = v[n][q];
-        }
+        for (int q = 0; q < R; ++q) dst(j0 + q * Ns, v[q]);
     }
     __syncthreads();
 }
 
-template <bool INV, typename V>
-__device__ void fft_inplace(V *x, const V *tw, const FftPlan &P) {
-    int Ns = 1;
-    for (int pass = 0; pass < P.nrad; ++pass) {
-        const int r = P.rad[pass];
-        const unsigned magic = P.magic[pass];
-        if (r == 4) pass_inplace<4, INV>(x, tw, P.n, Ns, magic);
-        else if (r == 2) pass_inplace<2, INV>(x, tw, P.n, Ns, magic);
-        else if (r == 3) pass_inplace<3, INV>(x, tw, P.n, Ns, magic);
-        else pass_inplace<5, INV>(x, tw, P.n, Ns, magic);
-        Ns *= r;
+template <int MAXR, bool INV, typename V, typename Src, typename Dst>
+__device__ __forceinline__ void pass_dispatch(int r1, int r2, const Src &src, const Dst &dst, bool fence, const V *tw,
+                                              int N, int Ns, unsigned magic) {
+#define GCM_PASS(A, B)                                                                      \
+    case (A) * 8 + (B):                                                                     \
+        if constexpr ((A) * (B) <= MAXR) composite_pass<A, B, INV>(src, dst, fence, tw, N, Ns, magic); \
+        break;
+    switch (r1 * 8 + r2) {
+        GCM_PASS(2, 1) GCM_PASS(3, 1) GCM_PASS(4, 1) GCM_PASS(5, 1)
+        GCM_PASS(3, 2) GCM_PASS(4, 2) GCM_PASS(3, 3) GCM_PASS(5, 2) GCM_PASS(4, 3)
+        GCM_PASS(5, 3) GCM_PASS(4, 4) GCM_PASS(5, 4) GCM_PASS(5, 5)
+        default: break;
     }
+#undef GCM_PASS
 }
 
-// in-place filter of the two rows packed in x[0..N); result left in x, scaled by 1/N
-template <typename T>
-__device__ void filter_rows_inplace(typename Vec2<T>::type *x, const PeArgsT<T> &a, int jglob) {
-    using T2 = typename Vec2<T>::type;
-    const int N = a.W;
-    fft_inplace<false>(x, a.tw, a.plan);
-    const T *S = a.smul + (long)jglob * (N / 2 + 1);
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        const T s = S[n <= N / 2 ? n : N - n];
-        x[n].x *= s;
-        x[n].y *= s;
-    }
-    __syncthreads();
-    fft_inplace<true>(x, a.tw, a.plan);
+// Filter the two real rows that `load(i)` delivers as re/im: forward FFT, multiply by S[n]/N
+// (n folded, low_pass.py:61-72; numpy's irfft scales by 1/N), inverse FFT, `store(i, V)`.
+template <int MAXR, typename T, typename Load, typename Store>
+__device__ __forceinline__ void filter_rows_composite(typename Vec2<T>::type *x, const Load &load, const Store &store,
+                                                      const typename Vec2<T>::type *tw, const SuperPlan &P, int N,
+                                                      const T *S) {
+    using V = typename Vec2<T>::type;
     const T inv_n = T(1.0) / (T)N;
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        x[n].x *= inv_n;
-        x[n].y *= inv_n;
+    const auto lds_src = [x](int i) { return x[i]; };
+    const auto lds_dst = [x](int i, V v) { x[i] = v; };
+    const auto lds_src_filtered = [x, S, N, inv_n](int i) {
+        const T s = S[i <= N / 2 ? i : N - i] * inv_n;
+        const V v = x[i];
+        return mkv<V>(v.x * s, v.y * s);
+    };
+    // the first and the last pass of either direction are written out rather than selected inside
+    // one loop: their global addresses would otherwise be hoisted out of it and pinned in registers
+    const int np = P.npass;
+    int Ns = P.r1[0] * P.r2[0];
+    pass_dispatch<MAXR, false>(P.r1[0], P.r2[0], load, lds_dst, false, tw, N, 1, P.magic[0]);
+    for (int pass = 1; pass < np; ++pass) {
+        pass_dispatch<MAXR, false>(P.r1[pass], P.r2[pass], lds_src, lds_dst, true, tw, N, Ns, P.magic[pass]);
+        Ns *= P.r1[pass] * P.r2[pass];
     }
-    __syncthreads();
+    if (np == 1) {
+        pass_dispatch<MAXR, true>(P.r1[0], P.r2[0], lds_src_filtered, store, false, tw, N, 1, P.magic[0]);
+        return;
+    }
+    pass_dispatch<MAXR, true>(P.r1[0], P.r2[0], lds_src_filtered, lds_dst, true, tw, N, 1, P.magic[0]);
+    Ns = P.r1[0] * P.r2[0];
+    for (int pass = 1; pass < np - 1; ++pass) {
+        pass_dispatch<MAXR, true>(P.r1[pass], P.r2[pass], lds_src, lds_dst, true, tw, N, Ns, P.magic[pass]);
+        Ns *= P.r1[pass] * P.r2[pass];
+    }
+    pass_dispatch<MAXR, true>(P.r1[np - 1], P.r2[np - 1], lds_src, store, false, tw, N, Ns, P.magic[np - 1]);
 }
 
 // filter two real rows held as re/im of x[0..N): FFT, multiply by S[n] (n folded), inverse FFT.
@@ -326,11 +394,12 @@ __device__ typename Vec2<T>::type *filter_rows(typename Vec2<T>::type *x, typena
 }
 
 // ---------------------------------------------------------------- K1: spu = filter(su * iph(sp))
-template <typename T>
-__global__ __launch_bounds__(kFftThreads) void pe_spu_filter_kernel(PeArgsT<T> a) {
-    using T2 = typename Vec2<T>::type;
+constexpr int kFftThreads = 256;    // generic path; the composite path sizes the workgroup from its plan
+template <typename T, int MAXR>
+__global__ __launch_bounds__(512) void pe_spu_filter_kernel(PeArgsT<T> a) {
+    using V = typename Vec2<T>::type;
     extern __shared__ unsigned char lds_raw[];
-    T2 *x = (T2 *)lds_raw, *y = x + a.W;
+    V *x = (V *)lds_raw;
     const Idx ix{a.W, a.H, a.L, a.wrap};
     const int j = a.j0 + blockIdx.x;
     const int k0 = 2 * blockIdx.y, k1 = k0 + 1;
@@ -339,21 +408,28 @@ __global__ __launch_bounds__(kFftThreads) void pe_spu_filter_kernel(PeArgsT<T> a
     const T *sp = a.sp + ix.r2(j);
     const T *su0 = a.su + ix.r3(j) + (long)k0 * W;
     const T *su1 = su0 + W;
-    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+    T *o0 = a.spu + ix.r3(j) + (long)k0 * W;
+    const auto load = [=](int i) {
         const int ie = i + 1 == W ? 0 : i + 1;
         const T pe = (sp[i] + sp[ie]) * T(0.5);      // iph(p), dynamics.py:15-17
-        x[i] = mkv<typename Vec2<T>::type>(su0[i] * pe, two ? su1[i] * pe : T(0.0));
-    }
-    __syncthreads();
-    T2 *res = x;
+        return mkv<V>(su0[i] * pe, two ? su1[i] * pe : T(0.0));
+    };
+    const auto store = [=](int i, V v) {
+        o0[i] = v.x;
+        if (two) o0[W + i] = v.y;
+    };
     if (a.filter && W > 1) {
-        if (a.plan.inplace) filter_rows_inplace(x, a, wrapi(a.row0 + j, a.Hg));
-        else res = filter_rows(x, y, a, wrapi(a.row0 + j, a.Hg));
-    }
-    T *o0 = a.spu + ix.r3(j) + (long)k0 * W;
-    for (int i = threadIdx.x; i < W; i += blockDim.x) {
-        o0[i] = res[i].x;
-        if (two) o0[W + i] = res[i].y;
+        if (MAXR > 0) {
+            const int jg = wrapi(a.row0 + j, a.Hg);
+            filter_rows_composite<MAXR, T>(x, load, store, a.tw, a.cplan, W, a.smul + (long)jg * (W / 2 + 1));
+        } else {
+            for (int i = threadIdx.x; i < W; i += blockDim.x) x[i] = load(i);
+            __syncthreads();
+            const V *res = filter_rows(x, x + W, a, wrapi(a.row0 + j, a.Hg));
+            for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, res[i]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, load(i));
     }
 }
 
@@ -434,11 +510,11 @@ __global__ __launch_bounds__(kColThreads) void pe_column_kernel(PeArgsT<T> a) {
 }
 
 // ---------------------------------------------------------------- K3: pgfu = filter(pgu + phiu)
-template <typename T>
-__global__ __launch_bounds__(kFftThreads) void pe_pgf_filter_kernel(PeArgsT<T> a) {
-    using T2 = typename Vec2<T>::type;
+template <typename T, int MAXR>
+__global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
+    using V = typename Vec2<T>::type;
     extern __shared__ unsigned char lds_raw[];
-    T2 *x = (T2 *)lds_raw, *y = x + a.W;
+    V *x = (V *)lds_raw;
     const Idx ix{a.W, a.H, a.L, a.wrap};
     const int j = a.j0 + blockIdx.x;
     const int k0 = 2 * blockIdx.y, k1 = k0 + 1;
@@ -447,35 +523,44 @@ __global__ __launch_bounds__(kFftThreads) void pe_pgf_filter_kernel(PeArgsT<T> a
     const int jg = wrapi(a.row0 + j, a.Hg);
     const T inv_dxj = a.inv_dxj[jg];
     const T *sp = a.sp + ix.r2(j);
-    const long o0 = ix.r3(j) + (long)k0 * W, o1 = o0 + W;
+    const long o0 = ix.r3(j) + (long)k0 * W;
+    const T *phi0 = a.phi + o0, *rho0 = a.rho + o0;
     const T sg0 = a.sig[k0], sg1 = two ? a.sig[k1] : T(0.0);
-    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+    T *out = a.pgfu + o0;
+    const auto load = [=](int i) {
         const int ie = i + 1 == W ? 0 : i + 1;
         const T pc = sp[i], pe = sp[ie];
         const T iphp = (pc + pe) * T(0.5);
         const T gradp = (pe - pc) * inv_dxj;
         T v[2] = {T(0.0), T(0.0)};
-        for (int s = 0; s < (two ? 2 : 1); ++s) {
-            const long o = s ? o1 : o0;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s == 1 && !two) break;
+            const T *phi = phi0 + s * W, *rho = rho0 + s * W;
             const T sg = s ? sg1 : sg0;
-            const T phiu = iphp * ((a.phi[o + ie] - a.phi[o + i]) * inv_dxj);      // dynamics.py:159
+            const T phiu = iphp * ((phi[ie] - phi[i]) * inv_dxj);                   // dynamics.py:159
             const T ppih = (sg * pc + sg * pe) * T(0.5);
-            const T rhou = (a.rho[o + i] + a.rho[o + ie]) * T(0.5);
+            const T rhou = (rho[i] + rho[ie]) * T(0.5);
             const T pgu = ppih * rcp(rhou) * gradp;                                 // dynamics.py:162-165
             v[s] = pgu + phiu;
         }
-        x[i] = mkv<typename Vec2<T>::type>(v[0], v[1]);
-    }
-    __syncthreads();
-    T2 *res = x;
+        return mkv<V>(v[0], v[1]);
+    };
+    const auto store = [=](int i, V v) {
+        out[i] = v.x;
+        if (two) out[W + i] = v.y;
+    };
     if (a.filter && W > 1) {
-        if (a.plan.inplace) filter_rows_inplace(x, a, jg);
-        else res = filter_rows(x, y, a, jg);
-    }
-    T *out = a.pgfu + o0;
-    for (int i = threadIdx.x; i < W; i += blockDim.x) {
-        out[i] = res[i].x;
-        if (two) out[W + i] = res[i].y;
+        if (MAXR > 0) {
+            filter_rows_composite<MAXR, T>(x, load, store, a.tw, a.cplan, W, a.smul + (long)jg * (W / 2 + 1));
+        } else {
+            for (int i = threadIdx.x; i < W; i += blockDim.x) x[i] = load(i);
+            __syncthreads();
+            const V *res = filter_rows(x, x + W, a, jg);
+            for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, res[i]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, load(i));
     }
 }
 
@@ -800,6 +885,7 @@ struct Pe25d {
     double *stage3 = nullptr;                   // float64 transpose staging, host layout
     double *exner_tab = nullptr;
     FftPlan plan{};
+    SuperPlan cplan{};
     double *gt = nullptr;                       // ground temperature [H][W] (column physics)
     double *rad_tab = nullptr;                  // 5 x [L] level tables of the last radiation call
     double *rad_geo = nullptr;                  // coslat[Hg], sinlat[Hg], lon[W]
@@ -826,12 +912,45 @@ static bool make_plan(int n, FftPlan *P) {
         P->magic[i] = (unsigned)(((1ULL << 32) + (unsigned long long)Ns - 1) / (unsigned long long)Ns);
         Ns *= P->rad[i];
     }
-    // in place when every pass is a {2,3,4,5} butterfly and its n / r butterflies fit the
-    // kMaxBfly register slots of the workgroup (2880 = 4.4.4.3.3.5: at most 960 per pass)
-    P->inplace = 1;
-    for (int i = 0; i < P->nrad; ++i)
-        if (P->rad[i] > 5 || n / P->rad[i] > kMaxBfly * kFftThreads) P->inplace = 0;
     return m == 1 && P->nrad <= kMaxRadices;
+}
+
+// composite-radix plan: n = product of base radices {5,4,3,2} (pairs of 2s become 4s), sorted
+// descending and paired largest-with-smallest into passes of radix r1 * r2 (1440 -> 5.2, 4.3, 4.3;
+// 2880 -> 5.3, 4.3, 4.4).  ok = 0 when n has a prime factor > 5 or a pass is wider than 512
+// butterflies (the workgroup has one thread per butterfly).
+static void make_super_plan(int n, SuperPlan *P) {
+    *P = SuperPlan{};
+    std::vector<int> base;
+    int m = n;
+    while (m % 5 == 0) { base.push_back(5); m /= 5; }
+    int twos = 0;
+    while (m % 2 == 0) { ++twos; m /= 2; }
+    for (int i = 0; i < twos / 2; ++i) base.push_back(4);
+    while (m % 3 == 0) { base.push_back(3); m /= 3; }
+    if (twos % 2) base.push_back(2);
+    if (m != 1 || base.empty()) return;
+    std::sort(base.begin(), base.end(), [](int x, int y) { return x > y; });
+    int lo = 0, hi = (int)base.size() - 1;
+    long Ns = 1;
+    int widest = 1;
+    while (lo <= hi) {
+        if (P->npass == kMaxSuper) return;
+        const int r1 = base[lo], r2 = lo < hi ? base[hi] : 1;
+        // 2 x 2 never occurs (pairs of 2s are 4s); r1 >= r2 by the sort
+        P->r1[P->npass] = r1;
+        P->r2[P->npass] = r2;
+        P->magic[P->npass] = (unsigned)(((1ULL << 32) + (unsigned long long)Ns - 1) / (unsigned long long)Ns);
+        Ns *= (long)r1 * r2;
+        if (r1 * r2 > P->maxr) P->maxr = r1 * r2;
+        if (n / (r1 * r2) > widest) widest = n / (r1 * r2);
+        ++P->npass;
+        ++lo;
+        --hi;
+    }
+    if (widest > 512) return;
+    P->threads = (widest + 63) / 64 * 64;
+    P->ok = 1;
 }
 
 template <typename T>
@@ -854,6 +973,29 @@ static bool upload_as(Pe25d *m, T **dst, const double *src, size_t count) {
 }
 
 static size_t rows_alloc(const Pe25d *m) { return (size_t)m->H + 2 * kGhost; }
+
+// the filter kernels are instantiated per widest composite radix (12 / 16 / 25), so that a plan
+// of small radices (1440 = 10.12.12) is not held to the register budget of a 25-point butterfly;
+// 0 = generic ping-pong passes
+template <typename T> using FilterKernel = void (*)(PeArgsT<T>);
+template <typename T>
+static FilterKernel<T> spu_filter_kernel_for(const SuperPlan &P) {
+    if (!P.ok) return pe_spu_filter_kernel<T, 0>;
+    if (P.maxr <= 12) return pe_spu_filter_kernel<T, 12>;
+    if (P.maxr <= 16) return pe_spu_filter_kernel<T, 16>;
+    return pe_spu_filter_kernel<T, 25>;
+}
+template <typename T>
+static FilterKernel<T> pgf_filter_kernel_for(const SuperPlan &P) {
+    if (!P.ok) return pe_pgf_filter_kernel<T, 0>;
+    if (P.maxr <= 12) return pe_pgf_filter_kernel<T, 12>;
+    if (P.maxr <= 16) return pe_pgf_filter_kernel<T, 16>;
+    return pe_pgf_filter_kernel<T, 25>;
+}
+template <typename T>
+static size_t filter_lds_bytes(const Pe25d *m) {
+    return (size_t)(m->cplan.ok ? 1 : 2) * m->W * sizeof(typename Vec2<T>::type);
+}
 
 template <typename T>
 static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
@@ -916,9 +1058,10 @@ static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
         }
         if (!dev_upload<T2>(m, &B.tw, tw.data(), W)) return "twiddles";
     }
-    const int lds_bytes = 2 * W * (int)sizeof(typename Vec2<T>::type);
-    if (hipFuncSetAttribute((const void *)pe_spu_filter_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute((const void *)pe_pgf_filter_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess ||
+    if (hipFuncSetAttribute((const void *)spu_filter_kernel_for<T>(m->cplan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)filter_lds_bytes<T>(m)) != hipSuccess ||
+        hipFuncSetAttribute((const void *)pgf_filter_kernel_for<T>(m->cplan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)filter_lds_bytes<T>(m)) != hipSuccess ||
         hipFuncSetAttribute((const void *)pe_column_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(L * kColThreads * sizeof(T))) != hipSuccess)
         return "dynamic LDS size";
@@ -963,6 +1106,7 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
         pe25d_destroy(m);
         return (Pe25d *)nullptr;
     };
+    if (W > 1) make_super_plan(W, &m->cplan);
     if (W > 1 && (!make_plan(W, &m->plan) || (size_t)W * 32 > 160 * 1024)) {
         *err = "GCM_PE25D: width not supported by the in-LDS FFT (too many factors or > 5120)";
         pe25d_destroy(m);
@@ -1060,6 +1204,7 @@ static PeArgsT<T> make_args(Pe25d *m, int stage_set, int out_set, double dt) {
     a.heightmap = Bf.heightmap; a.cor_u = Bf.cor_u; a.cor_v = Bf.cor_v; a.smul = Bf.smul; a.tw = Bf.tw;
     a.exner_tab = m->exner_tab;
     a.plan = m->plan;
+    a.cplan = m->cplan;
     a.W = m->W; a.H = m->H; a.L = m->L; a.Hg = m->Hg; a.row0 = m->cfg.row0;
     a.wrap = m->wrap ? 1 : 0;
     a.filter = m->cfg.filter;
@@ -1082,19 +1227,20 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
     PeArgsT<T> a = make_args<T>(m, stage_set, out_set, dt);
     const int W = m->W, L = m->L;
     const int ext = m->wrap ? 0 : 1;             // intermediates are also needed on row j1 (south)
-    const size_t lds = (size_t)(m->plan.inplace ? 1 : 2) * W * sizeof(typename Vec2<T>::type);
+    const size_t lds = filter_lds_bytes<T>(m);
+    const int fft_threads = m->cplan.ok ? m->cplan.threads : kFftThreads;
     const int pairs = (L + 1) / 2;
     if (mode != 2) {
         a.j0 = j0;
         a.j1 = j1 + ext;
-        hipLaunchKernelGGL(pe_spu_filter_kernel<T>, dim3(a.j1 - a.j0, pairs), dim3(kFftThreads), lds, s, a);
+        hipLaunchKernelGGL(spu_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, s, a);
         {
             const long tiles = (long)((W + kColThreads - 1) / kColThreads) * (a.j1 - a.j0);
             hipLaunchKernelGGL(pe_column_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kColThreads),
                                sizeof(T) * (size_t)L * kColThreads, s, a);
         }
         a.j1 = j1;
-        hipLaunchKernelGGL(pe_pgf_filter_kernel<T>, dim3(a.j1 - a.j0, pairs), dim3(kFftThreads), lds, s, a);
+        hipLaunchKernelGGL(pgf_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, s, a);
     }
     auto update_rows = [&](int r0, int r1) {
         if (r1 <= r0) return;
