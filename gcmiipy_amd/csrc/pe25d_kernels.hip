@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "gcm_math.h"
@@ -433,12 +434,15 @@ __global__ __launch_bounds__(512) void pe_spu_filter_kernel(PeArgsT<T> a) {
     }
 }
 
-// ---------------------------------------------------------------- K2: column kernel
-// The per-level values that the two scans need twice (conv for the reverse cumulative sum,
-// stp for phi) are parked in LDS, park[k][thread], instead of a round trip through HBM.
+// ---------------------------------------------------------------- K2: column kernels
+// K2a pe_geopot_kernel: rho, phi from the stage theta and surface pressure (compute_geopotential);
+// K2b pe_pit_kernel: pit = sum_k conv and p_n from the filtered mass flux (aflux).  They are two
+// kernels because they sit on two independent chains, K1 -> K2b and K2a -> K3 (see half_t).
+// The per-level stp that phi needs after the column sum is parked in LDS, park[k][thread],
+// instead of a round trip through HBM.
 constexpr int kColThreads = 128;
 template <typename T>
-__global__ __launch_bounds__(kColThreads) void pe_column_kernel(PeArgsT<T> a) {
+__global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
     __shared__ double tab[kExnerTabDoubles];
     extern __shared__ unsigned char park_raw[];
     T *park = (T *)park_raw;                    // [L][kColThreads]
@@ -456,23 +460,9 @@ __global__ __launch_bounds__(kColThreads) void pe_column_kernel(PeArgsT<T> a) {
     const int j = a.j0 + jrel;
     if (i >= W) return;
     T *pk = park + threadIdx.x;
-    const int iw = i == 0 ? W - 1 : i - 1;
     const int jg = wrapi(a.row0 + j, a.Hg);
-    const T inv_dxj = a.inv_dxj[jg], inv_dy = a.inv_dy;
-    const T spc = a.sp[ix.r2(j) + i], spn = a.sp[ix.r2(j - 1) + i], sps = a.sp[ix.r2(j + 1) + i];
-    const T jph_c = (spc + sps) * T(0.5), jph_n = (spn + spc) * T(0.5);  // jph(sp) at j, j-1
-    const long c3 = ix.r3(j), n3 = ix.r3(j - 1);
-    // ---- aflux, dynamics.py:35-46: pit = sum_k conv (ascending, as np.sum over the outer axis).
-    // sigma-dot itself is not materialised: the update kernel rebuilds it on the fly from pit.
-    T pit = T(0.0);
-    for (int k = 0; k < L; ++k) {
-        const long o = c3 + (long)k * W;
-        const T spv_c = a.sv[o + i] * jph_c;
-        const T spv_n = a.sv[n3 + (long)k * W + i] * jph_n;
-        pit += ((a.spu[o + i] - a.spu[o + iw]) * inv_dxj + (spv_c - spv_n) * inv_dy) * a.dsig[k];
-    }
-    a.pit[ix.r2(j) + i] = pit;
-    a.pn[ix.r2(j) + i] = a.p[ix.r2(j) + i] - pit * a.dt;   // p_n = p - pit dt, dynamics.py:194
+    const T spc = a.sp[ix.r2(j) + i];
+    const long c3 = ix.r3(j);
     // ---- compute_geopotential, dynamics.py:111-143
     const T hmG = a.heightmap ? a.heightmap[(long)jg * W + i] * T(kG) : T(0.0) * T(kG);
     T t_k = a.st[c3 + i];
@@ -507,6 +497,39 @@ __global__ __launch_bounds__(kColThreads) void pe_column_kernel(PeArgsT<T> a) {
         run += pk[(k - 1) * kColThreads];
         a.phi[c3 + (long)k * W + i] = run;
     }
+}
+
+// aflux, dynamics.py:35-46: pit = sum_k conv (ascending, as np.sum over the outer axis) and
+// p_n = p - pit dt (dynamics.py:194).  sigma-dot itself is not materialised: the update kernel
+// rebuilds it on the fly from pit.
+template <typename T>
+__global__ __launch_bounds__(256) void pe_pit_kernel(PeArgsT<T> a) {
+    const Idx ix{a.W, a.H, a.L, a.wrap};
+    const int W = a.W, L = a.L;
+    const int iblocks = (W + 255) / 256;
+    const int per_xcd = gridDim.x / 8;
+    const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const int jrel = tile / iblocks;
+    if (jrel >= a.j1 - a.j0) return;
+    const int i = (tile - jrel * iblocks) * 256 + threadIdx.x;
+    const int j = a.j0 + jrel;
+    if (i >= W) return;
+    const int iw = i == 0 ? W - 1 : i - 1;
+    const int jg = wrapi(a.row0 + j, a.Hg);
+    const T inv_dxj = a.inv_dxj[jg], inv_dy = a.inv_dy;
+    const T spc = a.sp[ix.r2(j) + i], spn = a.sp[ix.r2(j - 1) + i], sps = a.sp[ix.r2(j + 1) + i];
+    const T jph_c = (spc + sps) * T(0.5), jph_n = (spn + spc) * T(0.5);  // jph(sp) at j, j-1
+    const long c3 = ix.r3(j), n3 = ix.r3(j - 1);
+    T pit = T(0.0);
+#pragma unroll 4
+    for (int k = 0; k < L; ++k) {
+        const long o = c3 + (long)k * W;
+        const T spv_c = a.sv[o + i] * jph_c;
+        const T spv_n = a.sv[n3 + (long)k * W + i] * jph_n;
+        pit += ((a.spu[o + i] - a.spu[o + iw]) * inv_dxj + (spv_c - spv_n) * inv_dy) * a.dsig[k];
+    }
+    a.pit[ix.r2(j) + i] = pit;
+    a.pn[ix.r2(j) + i] = a.p[ix.r2(j) + i] - pit * a.dt;
 }
 
 // ---------------------------------------------------------------- K3: pgfu = filter(pgu + phiu)
@@ -892,6 +915,8 @@ struct Pe25d {
     double rad_key[2] = {-1.0, -1.0};           // (t_lw, t_sw) the level tables were built for
     std::vector<hipEvent_t> *ev = nullptr;
     size_t *ev_used = nullptr;
+    hipStream_t aux = nullptr;                  // second stream of a stage (K2a -> K3), see half_t
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 template <typename T> static PeBufs<T> &bufs(Pe25d *m);
@@ -1062,7 +1087,7 @@ static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
                             (int)filter_lds_bytes<T>(m)) != hipSuccess ||
         hipFuncSetAttribute((const void *)pgf_filter_kernel_for<T>(m->cplan), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)filter_lds_bytes<T>(m)) != hipSuccess ||
-        hipFuncSetAttribute((const void *)pe_column_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void *)pe_geopot_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(L * kColThreads * sizeof(T))) != hipSuccess)
         return "dynamic LDS size";
     return nullptr;
@@ -1122,11 +1147,21 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
     double tab[kExnerTabDoubles];
     build_exner_table(tab);
     if (!dev_upload(m, &m->exner_tab, tab, kExnerTabDoubles)) return bad("exner table");
+    const char *no_aux = getenv("GCM_PE_SINGLE_STREAM");      // diagnostic: one chain, one stream
+    if (!(no_aux && no_aux[0] == '1')) {
+        if (hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess)
+            return bad("second stream");
+    }
     return m;
 }
 
 void pe25d_destroy(Pe25d *m) {
     if (!m) return;
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->aux) (void)hipStreamDestroy(m->aux);
     for (void *p : m->allocs) (void)hipFree(p);
     delete m;
 }
@@ -1231,16 +1266,32 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
     const int fft_threads = m->cplan.ok ? m->cplan.threads : kFftThreads;
     const int pairs = (L + 1) / 2;
     if (mode != 2) {
+        // two independent chains: K1 -> K2b (mass flux, pit) on the caller's stream, K2a -> K3
+        // (geopotential, filtered pressure-gradient force) on the handle's second stream.  The FFT
+        // kernels are latency bound and the column kernels bandwidth bound, so they share the chip.
+        hipStream_t s2 = m->aux ? m->aux : s;
+        if (m->aux) {
+            (void)hipEventRecord(m->ev_fork, s);
+            (void)hipStreamWaitEvent(m->aux, m->ev_fork, 0);
+        }
         a.j0 = j0;
         a.j1 = j1 + ext;
-        hipLaunchKernelGGL(spu_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, s, a);
         {
             const long tiles = (long)((W + kColThreads - 1) / kColThreads) * (a.j1 - a.j0);
-            hipLaunchKernelGGL(pe_column_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kColThreads),
-                               sizeof(T) * (size_t)L * kColThreads, s, a);
+            hipLaunchKernelGGL(pe_geopot_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kColThreads),
+                               sizeof(T) * (size_t)L * kColThreads, s2, a);
+        }
+        hipLaunchKernelGGL(spu_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, s, a);
+        {
+            const long tiles = (long)((W + 255) / 256) * (a.j1 - a.j0);
+            hipLaunchKernelGGL(pe_pit_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, s, a);
         }
         a.j1 = j1;
-        hipLaunchKernelGGL(pgf_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, s, a);
+        hipLaunchKernelGGL(pgf_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, s2, a);
+        if (m->aux) {
+            (void)hipEventRecord(m->ev_join, m->aux);
+            (void)hipStreamWaitEvent(s, m->ev_join, 0);
+        }
     }
     auto update_rows = [&](int r0, int r1) {
         if (r1 <= r0) return;
