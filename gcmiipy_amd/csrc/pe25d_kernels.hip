@@ -5,11 +5,13 @@
 // latitude band and its ghost rows are contiguous slabs; p is [j][i].  The host-facing layout
 // stays the reference's [k][j][i]; set/get transpose on the device.
 //
-// One half_timestep (dynamics.py:183-227) is four launches:
-//   K1 spu_filter   spu = arakawa_1977(su * iph(sp))            one workgroup per (row, level pair)
-//   K2 column       conv, pit, p_n; rho, phi (sigma-dot is rebuilt in K4)  one thread per (j, i) column
-//   K3 pgf_filter   pgfu = arakawa_1977(pgu + phiu)              one workgroup per (row, level pair)
-//   K4 update       advec_m_pu, advec_sig, advec_t, un_pu/un_pv  one thread per cell
+// One half_timestep (dynamics.py:183-227) is five launches on two streams:
+//   K1  spu_filter  spu = arakawa_1977(su * iph(sp))            one workgroup per (row, level pair)
+//   K2b pit         conv, pit, p_n (sigma-dot is rebuilt in K4)  one thread per (j, i) column
+//   K2a geopot      rho, phi                                     one thread per (j, i) column
+//   K3  pgf_filter  pgfu = arakawa_1977(pgu + phiu)              one workgroup per (row, level pair)
+//   K4  update      advec_m_pu, advec_sig, advec_t, un_pu/un_pv  one thread per (j, i) column
+// K1 -> K2b and K2a -> K3 are independent chains (two streams), K4 needs both.
 // The zonal filter is a complex Stockham FFT in LDS: two levels of one row are packed as
 // real and imaginary part (the filter multiplier is real and symmetric in the wavenumber, so
 // it acts on both parts independently), multiplied by S[j][n] and transformed back.
