@@ -35,6 +35,7 @@ struct FftPlan {
     unsigned magic[kMaxRadices];   // ceil(2^32 / Ns) per pass: b / Ns == umulhi(b, magic) for b*Ns < 2^32
 };
 
+constexpr int kMaxSeg = 4;      // level segments of the update kernel (short bands)
 constexpr int kMaxSuper = 8;
 struct SuperPlan {
     int ok;                        // 0: use the generic ping-pong path
@@ -63,6 +64,7 @@ struct PeArgsT {
     // intermediates
     T *spu, *phi, *rho, *pgfu;        // 3-D
     T *pit, *pn;                      // 2-D
+    T *part;                          // [nseg-1] 2-D slabs: conv summed from the top down to a segment boundary
     // tables (device)
     const T *inv_dxj, *inv_dxh;       // [Hg] reciprocals of geometry.py:136-137
     const T *sig, *dsig, *inv_dsig, *sigb, *sigt;  // [L]
@@ -77,6 +79,9 @@ struct PeArgsT {
     int wrap;                              // 1: rows wrap modulo H (single band)
     int filter;
     int j0, j1;                            // rows to produce
+    int jb0, jb1;                          // second row range of the same launch (K4 edge rows), or empty
+    int nseg;                              // K4 marches the column in nseg level segments (1: whole column)
+    long part_stride;                      // elements per slab of `part`
     T dt, inv_dy, ptop;
 };
 
@@ -436,6 +441,25 @@ __global__ __launch_bounds__(512) void pe_spu_filter_kernel(PeArgsT<T> a) {
     }
 }
 
+// The update kernel may march a column in several level segments (short latitude bands: more,
+// shorter workgroups).  Segment s covers levels [seg_lo(s), seg_lo(s+1)); the running sum of conv
+// from the top that sigma-dot needs (dynamics.py:42) then starts from a partial sum that
+// pe_pit_kernel leaves at every segment boundary.  Both kernels accumulate through these two
+// functions with explicit fma, so that the partial sums are bit-identical to what an unsplit march
+// has at that level and the result does not depend on the number of segments.
+__device__ __forceinline__ int seg_lo(int s, int nseg, int L) { return (int)((long)s * L / nseg); }
+// acc + ((fx_hi - fx_lo) / dx + (sv_hi jph_hi - sv_lo jph_lo) / dy) dsig; the meridional flux
+// products are formed in here: handed over as values, one kernel might fuse them into the
+// difference and the other not
+template <typename T>
+__device__ __forceinline__ T conv_acc(T acc, T fx_hi, T fx_lo, T inv_dx, T sv_hi, T jph_hi, T sv_lo, T jph_lo,
+                                      T inv_dy, T dsg) {
+    const T dy = fma(sv_hi, jph_hi, -(sv_lo * jph_lo));
+    return fma(fma(fx_hi - fx_lo, inv_dx, dy * inv_dy), dsg, acc);
+}
+template <typename T>
+__device__ __forceinline__ T sd_of(T rc, T pit, T sgb) { return fma(-pit, sgb, rc); }
+
 // ---------------------------------------------------------------- K2: column kernels
 // K2a pe_geopot_kernel: rho, phi from the stage theta and surface pressure (compute_geopotential);
 // K2b pe_pit_kernel: pit = sum_k conv and p_n from the filtered mass flux (aflux).  They are two
@@ -532,6 +556,22 @@ __global__ __launch_bounds__(256) void pe_pit_kernel(PeArgsT<T> a) {
     }
     a.pit[ix.r2(j) + i] = pit;
     a.pn[ix.r2(j) + i] = a.p[ix.r2(j) + i] - pit * a.dt;
+    if (a.nseg > 1) {
+        // top-down partial sums at the segment boundaries, exactly as pe_update_kernel accumulates
+        T rc = T(0.0);
+        int s = a.nseg - 2;
+        int stop = seg_lo(s + 1, a.nseg, L);
+        for (int k = L - 1; k >= 1 && s >= 0; --k) {
+            const long o = c3 + (long)k * W;
+            rc = conv_acc(rc, a.spu[o + i], a.spu[o + iw], inv_dxj, a.sv[o + i], jph_c, a.sv[n3 + (long)k * W + i], jph_n,
+                          inv_dy, a.dsig[k]);
+            if (k == stop) {
+                a.part[(long)s * a.part_stride + ix.r2(j) + i] = rc;
+                --s;
+                if (s >= 0) stop = seg_lo(s + 1, a.nseg, L);
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------- K3: pgfu = filter(pgu + phiu)
@@ -602,10 +642,14 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgsT<T> a) {
     const int iblocks = (W + 255) / 256;
     const int per_xcd = gridDim.x / 8;
     const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    const int jrel = tile / iblocks;
-    if (jrel >= a.j1 - a.j0) return;                          // padding tiles
-    const int j = a.j0 + jrel;
-    const int i = (tile - jrel * iblocks) * 256 + threadIdx.x;
+    // tile = ((row, level segment), column block); rows come from [j0, j1) then [jb0, jb1)
+    const int nseg = a.nseg;
+    const int rowseg = tile / iblocks;
+    const int jrel = rowseg / nseg, seg = rowseg - jrel * nseg;
+    const int na = a.j1 - a.j0;
+    if (jrel >= na + (a.jb1 - a.jb0)) return;                // padding tiles
+    const int j = jrel < na ? a.j0 + jrel : a.jb0 + (jrel - na);
+    const int i = (tile - rowseg * iblocks) * 256 + threadIdx.x;
     if (i >= W) return;
     const int iw = i == 0 ? W - 1 : i - 1, ie = i + 1 == W ? 0 : i + 1;
     const int jg = wrapi(a.row0 + j, a.Hg);
@@ -627,7 +671,7 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgsT<T> a) {
     const bool pole_edge = jg == a.Hg - 1;
     const bool coriolis = a.cor_u != nullptr;
     const T cp_u = coriolis ? a.cor_u[jg] : T(0.0), cp_v = coriolis ? a.cor_v[jg] : T(0.0);
-    a.op[(long)j * W + i] = pn_c;
+    if (seg == 0) a.op[(long)j * W + i] = pn_c;
 
     // The levels are marched from the top down, because sigma-dot is the top-down running sum of
     // conv (dynamics.py:42: cumsum(conv[::-1])[::-1] - pit sigb, sd[0] = 0): it is rebuilt here,
@@ -635,14 +679,29 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgsT<T> a) {
     // the momentum advection loads anyway, instead of being read back from HBM.
     // Vertical window: level k+1 (p), k (c), k-1 (m).  kp()/km() wrap (coordinates_3d.py:55-60):
     // level L is 0 and level -1 is L-1; both only ever meet sd[0] = T(0.)
+    // This workgroup marches levels [k_lo, k_hi) of its columns (the whole column if nseg == 1).
     const T inv_dxj_s = a.inv_dxj[wrapi(a.row0 + j + 1, a.Hg)];
     const T pit_c = a.pit[p_c + i], pit_e = a.pit[p_c + ie], pit_s = a.pit[p_s + i];
+    const int k_lo = seg_lo(seg, nseg, L), k_hi = seg_lo(seg + 1, nseg, L);
+    if (k_hi <= k_lo) return;
     const long top = (long)(L - 1) * W;
-    T su_p = a.su[rc + i], sv_p = a.sv[rc + i], st_p = a.st[rc + i], sq_p = a.sq[rc + i];   // level L -> 0
-    T su_c = a.su[rc + top + i], sv_c = a.sv[rc + top + i], st_c = a.st[rc + top + i], sq_c = a.sq[rc + top + i];
-    T sd_cp = T(0.0), sd_ep = T(0.0), sd_sp = T(0.0);            // sd at level k+1; level L wraps to sd[0] = 0
-    T rc_c = T(0.0), rc_e = T(0.0), rc_s = T(0.0);               // running sums of conv from the top
-    for (int k = L - 1; k >= 0; --k) {
+    const long kp0 = k_hi == L ? 0 : (long)k_hi * W;            // level k_hi; level L wraps to 0
+    const long kc0 = (long)(k_hi - 1) * W;
+    T su_p = a.su[rc + kp0 + i], sv_p = a.sv[rc + kp0 + i], st_p = a.st[rc + kp0 + i], sq_p = a.sq[rc + kp0 + i];
+    T su_c = a.su[rc + kc0 + i], sv_c = a.sv[rc + kc0 + i], st_c = a.st[rc + kc0 + i], sq_c = a.sq[rc + kc0 + i];
+    // running sums of conv from the top and sd at level k_hi: zero above the top level, else from
+    // the partial sums pe_pit_kernel left at this segment boundary
+    T rc_c = T(0.0), rc_e = T(0.0), rc_s = T(0.0);
+    T sd_cp = T(0.0), sd_ep = T(0.0), sd_sp = T(0.0);
+    if (k_hi < L) {
+        const T *part = a.part + (long)seg * a.part_stride;
+        const T sgb_hi = a.sigb[k_hi];
+        rc_c = part[p_c + i]; rc_e = part[p_c + ie]; rc_s = part[p_s + i];
+        sd_cp = sd_of(rc_c, pit_c, sgb_hi);
+        sd_ep = sd_of(rc_e, pit_e, sgb_hi);
+        sd_sp = sd_of(rc_s, pit_s, sgb_hi);
+    }
+    for (int k = k_hi - 1; k >= k_lo; --k) {
         const long kc = (long)k * W;
         T su_m, sv_m, st_m, sq_m;
         if (k > 0) {
@@ -666,12 +725,12 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgsT<T> a) {
         const T dsg = a.dsig[k], sgb = a.sigb[k];
         T sd_c = T(0.0), sd_e = T(0.0), sd_s = T(0.0);           // sd[0] = 0, dynamics.py:44
         if (k > 0) {
-            rc_c += ((spu_c - spu_w) * inv_dxj + (spv_c - spv_n) * inv_dy) * dsg;
-            rc_e += ((spu_e - spu_c) * inv_dxj + (spv_e - spv_ne) * inv_dy) * dsg;
-            rc_s += ((spu_s - spu_sw) * inv_dxj_s + (spv_s - spv_c) * inv_dy) * dsg;
-            sd_c = rc_c - pit_c * sgb;
-            sd_e = rc_e - pit_e * sgb;
-            sd_s = rc_s - pit_s * sgb;
+            rc_c = conv_acc(rc_c, spu_c, spu_w, inv_dxj, sv_c, jph_c, sv_n, jph_n, inv_dy, dsg);
+            rc_e = conv_acc(rc_e, spu_e, spu_c, inv_dxj, sv_e, jph_ce, sv_ne, jph_ne, inv_dy, dsg);
+            rc_s = conv_acc(rc_s, spu_s, spu_sw, inv_dxj_s, sv_s, jph_s, sv_c, jph_c, inv_dy, dsg);
+            sd_c = sd_of(rc_c, pit_c, sgb);
+            sd_e = sd_of(rc_e, pit_e, sgb);
+            sd_s = sd_of(rc_s, pit_s, sgb);
         }
         // ---- advec_m_pu, dynamics.py:55-108
         const T puum = ((su_c + su_w) * T(0.5)) * ((spu_c + spu_w) * T(0.5));
@@ -890,6 +949,7 @@ struct PeBufs {
     // state sets: 0/1 ping-pong (cur = set[cur_i]), 2 = star.  [f] p,u,v,t,q; interior pointers
     T *st[3][GCM_NFIELDS] = {};
     T *spu = nullptr, *phi = nullptr, *rho = nullptr, *pgfu = nullptr, *pit = nullptr, *pn = nullptr;
+    T *part = nullptr;                          // (kMaxSeg - 1) slabs like pit
     T *cor_u = nullptr, *cor_v = nullptr;
     T *inv_dxj = nullptr, *inv_dxh = nullptr, *sig = nullptr, *dsig = nullptr, *inv_dsig = nullptr,
       *sigb = nullptr, *sigt = nullptr, *heightmap = nullptr, *smul = nullptr;
@@ -906,6 +966,7 @@ struct Pe25d {
     PeBufs<float> f;
     int cur_i = 0;
     bool star_valid = false;
+    int nseg = 1;                               // level segments of K4, chosen from the band's size
     int pack_set = -1;                          // >= 0: state set gcm_halo_pack reads (step_phase)
     double *stage3 = nullptr;                   // float64 transpose staging, host layout
     double *exner_tab = nullptr;
@@ -1047,6 +1108,11 @@ static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
         if (!dev_upload<T>(m, &d, nullptr, n2)) return "intermediate";
         *pp = d + (size_t)kGhost * W;
     }
+    {
+        T *d = nullptr;
+        if (!dev_upload<T>(m, &d, nullptr, n2 * (kMaxSeg - 1))) return "intermediate";
+        B.part = d + (size_t)kGhost * W;
+    }
     // tables
     std::vector<double> idj(Hg), idh(Hg), ids(L);
     for (int j = 0; j < Hg; ++j) {
@@ -1144,6 +1210,19 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
         pe25d_destroy(m);
         return nullptr;
     }
+    {
+        // K4 runs 2 workgroups of 256 columns per CU; a band with fewer column blocks than about
+        // four rounds of that splits the level march, so that the kernel is several short rounds
+        // instead of one or two long ones (results do not depend on the split)
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        const long tiles = (long)((W + 255) / 256) * m->H;
+        long want = (4L * 2 * cus + tiles - 1) / tiles;
+        if (const char *e = getenv("GCM_PE_LEVEL_SEGMENTS")) want = atoi(e);
+        const int cap = std::min(kMaxSeg, std::max(1, L / 4));
+        m->nseg = (int)std::max(1L, std::min((long)cap, want));
+    }
     if (const char *what = m->f32 ? alloc_all<float>(m, cfg) : alloc_all<double>(m, cfg)) return bad(what);
     if (!dev_upload<double>(m, &m->stage3, nullptr, (size_t)m->H * W * L)) return bad("staging");
     double tab[kExnerTabDoubles];
@@ -1236,6 +1315,9 @@ static PeArgsT<T> make_args(Pe25d *m, int stage_set, int out_set, double dt) {
     a.op = O[GCM_P]; a.ou = O[GCM_U]; a.ov = O[GCM_V]; a.ot = O[GCM_T]; a.oq = O[GCM_Q];
     a.spu = Bf.spu; a.phi = Bf.phi; a.rho = Bf.rho; a.pgfu = Bf.pgfu;
     a.pit = Bf.pit; a.pn = Bf.pn;
+    a.part = Bf.part;
+    a.part_stride = (long)rows_alloc(m) * m->W;
+    a.nseg = m->nseg;
     a.inv_dxj = Bf.inv_dxj; a.inv_dxh = Bf.inv_dxh;
     a.sig = Bf.sig; a.dsig = Bf.dsig; a.inv_dsig = Bf.inv_dsig; a.sigb = Bf.sigb; a.sigt = Bf.sigt;
     a.heightmap = Bf.heightmap; a.cor_u = Bf.cor_u; a.cor_v = Bf.cor_v; a.smul = Bf.smul; a.tw = Bf.tw;
@@ -1295,25 +1377,27 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
             (void)hipStreamWaitEvent(s, m->ev_join, 0);
         }
     }
-    auto update_rows = [&](int r0, int r1) {
-        if (r1 <= r0) return;
+    auto update_rows = [&](int r0, int r1, int rb0, int rb1) {     // rows [r0, r1) and [rb0, rb1), one launch
+        const int rows = std::max(0, r1 - r0) + std::max(0, rb1 - rb0);
+        if (rows <= 0) return;
         a.j0 = r0;
-        a.j1 = r1;
-        const long tiles = (long)((W + 255) / 256) * (r1 - r0);
+        a.j1 = std::max(r0, r1);
+        a.jb0 = rb0;
+        a.jb1 = std::max(rb0, rb1);
+        const long tiles = (long)((W + 255) / 256) * rows * a.nseg;
         hipLaunchKernelGGL(pe_update_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, s, a);
     };
     const bool split = mode != 0 && (j1 - j0) > 2 * kGhost;
     if (mode == 0 || !split) {
         if (mode != 2) {      // an unsplittable (tiny) band does all of K4 in mode 1
             tick(m, s);
-            update_rows(j0, j1);
+            update_rows(j0, j1, 0, 0);
             tick(m, s);
         }
     } else if (mode == 1) {
-        update_rows(j0, j0 + kGhost);
-        update_rows(j1 - kGhost, j1);
+        update_rows(j0, j0 + kGhost, j1 - kGhost, j1);
     } else {
-        update_rows(j0 + kGhost, j1 - kGhost);
+        update_rows(j0 + kGhost, j1 - kGhost, 0, 0);
     }
 }
 

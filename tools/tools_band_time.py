@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Compute-side strong-scaling bound, measured on ONE GPU.
+
+For N in --splits, builds the band a middle rank of an N-way latitude split would own
+(bench.py's workloads and synthetic state), and steps it with exactly the launches the band
+engine issues (gcmiipy_amd.bands.HipBandEngine: edge-first phases for GCM_PE25D, deep-halo
+windows for the 2-D models), with the ghost-row exchange replaced by a device-local copy
+of the band's own edge rows (send buffer -> receive buffer on the second stream).  The numbers
+say how far the kernels alone let the step shrink when the grid is split N ways -- the exchange
+over xGMI then has to hide behind them.  The 8-GPU runs themselves are the driver's.
+
+  python tools/tools_band_time.py [--workload c4|c3] [--splits 1,2,4,8] [--steps 20]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class LoopbackDist:
+    """stands in for torch.distributed inside BandRunner: every send lands in the matching
+    receive buffer of the same rank (north edge -> south ghost and vice versa)."""
+
+    class _Req:
+        def wait(self):
+            pass
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    isend, irecv = "isend", "irecv"
+
+    def batch_isend_irecv(self, ops):
+        sends = [o.tensor for o in ops if o.op == "isend"]
+        recvs = [o.tensor for o in ops if o.op == "irecv"]
+        for s, r in zip(sends, recvs):     # BandRunner's order: sends N,S; receives S,N
+            r.copy_(s, non_blocking=True)
+        return [self._Req()]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c4")
+    ap.add_argument("--splits", default="1,2,4,8")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    import torch
+    import bench
+    import gcmiipy_amd as g
+    from gcmiipy_amd import _lib, geometry
+    from gcmiipy_amd.bands import BandRunner, HipBandEngine, split_rows
+    torch.cuda.set_device(0)
+    desc, H, W, L, model, tracer, bpc, dt = bench.WORKLOADS[a.workload]
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig) if model == "PE25D" else None
+    full = bench.synth(a.workload, H, W, L, geom=geom)
+    res = []
+    for n in [int(x) for x in a.splits.split(",")]:
+        rank = n // 2
+        row0, nrows = split_rows(H, n)[rank]
+        k = bench.halo_steps_for(a.workload, n)
+        core = g.Core(getattr(_lib, model), W, nrows, L, dx=bench.DX, geom=geom,
+                      tracer={None: _lib.TRACER_NONE, "van_leer": _lib.TRACER_VANLEER}[tracer],
+                      nranks=n, rank=rank, global_height=H, row0=row0,
+                      stream=torch.cuda.current_stream().cuda_stream, halo_steps=k,
+                      dtype="f32" if a.workload.endswith("_f32") else "f64")
+        sl = slice(row0, row0 + nrows)
+        core.set_state(**{f: (x[sl] if x.ndim == 2 else x[:, sl]) for f, x in full.items()})
+        eng = HipBandEngine(core, torch) if n > 1 else None
+        runner = BandRunner(eng, rank, n, LoopbackDist() if n > 1 else None)
+        if n == 1:
+            runner.e = type("E", (), {"step_all": staticmethod(lambda dt_: core.step(1, dt_))})()
+        steps = (a.steps + k - 1) // k * k
+        runner.run(max(2 * k, 4), dt)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        runner.run(steps, dt)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        res.append({"split": n, "band_rows": nrows, "halo_steps": k, "ms_per_step": ms})
+        print("N=%d  band of %4d rows  %.4f ms/step" % (n, nrows, ms), flush=True)
+        core.close()
+    base = res[0]["ms_per_step"] if res and res[0]["split"] == 1 else None
+    for r in res:
+        if base:
+            r["compute_bound_speedup"] = base / r["ms_per_step"]
+    doc = {"workload": desc, "note": "one band of an N-way split stepped on one GPU, exchange replaced by a "
+           "device-local copy: the kernels' own strong-scaling bound", "bands": res}
+    print(json.dumps(doc))
+    if a.out:
+        with open(os.path.join(ROOT, a.out), "w") as f:
+            f.write(json.dumps(doc, indent=1) + "\n")
+
+
+if __name__ == "__main__":
+    main()
