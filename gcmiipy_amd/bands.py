@@ -47,6 +47,11 @@ class BandRunner:
         compute_after(phase, dt)        the rest of the phase
         step_all(dt)                    single-band step (nranks == 1)
         comm_begin() / comm_end()       stream fencing around the exchange (GPU engines)
+    optional:
+        pack_both() -> (north, south) / unpack_both()    both sides with one launch each
+        edge_first + compute_edges(stage, dt) / compute_interior(stage, dt)   GCM_PE25D phases
+        mark_packed()                   the next comm_begin() waits for the work queued so far only
+        steps_per_exchange, step_n(n, dt)               deep halo
     """
 
     def __init__(self, engine, rank, nranks, dist=None):
@@ -58,9 +63,23 @@ class BandRunner:
         self._ops = None
         self.primed = False
 
-    def exchange_start(self):
+    def _pack(self):
+        """-> (north send buffer, south send buffer), packed"""
+        e = self.e
+        if hasattr(e, "pack_both"):
+            return e.pack_both()
+        return e.send_buffer(0), e.send_buffer(1)
+
+    def _unpack(self):
+        if hasattr(self.e, "unpack_both"):
+            self.e.unpack_both()
+        else:
+            self.e.unpack(0)
+            self.e.unpack(1)
+
+    def exchange_start(self, packed=None):
         d, e = self.dist, self.e
-        sn, ss = e.send_buffer(0), e.send_buffer(1)
+        sn, ss = self._pack() if packed is None else packed
         e.comm_begin()
         # order matters when both neighbours are the same peer (N == 2): sends go
         # north-edge first, receives take the south ghost first (it is the peer's
@@ -73,53 +92,41 @@ class BandRunner:
                           d.P2POp(d.irecv, rs, self.south), d.P2POp(d.irecv, rn, self.north)])
         return d.batch_isend_irecv(self._ops[1])
 
+    def _finish(self, reqs):
+        for r in reqs:
+            r.wait()
+        self.e.comm_end()
+        self._unpack()
+
     def step(self, dt):
         if self.n == 1:
             self.e.step_all(dt)
             return
         if self.k > 1:                      # deep halo: exchange, then k purely local steps
             if self.count % self.k == 0:
-                reqs = self.exchange_start()
-                for r in reqs:
-                    r.wait()
-                self.e.comm_end()
-                self.e.unpack(0)
-                self.e.unpack(1)
+                self._finish(self.exchange_start())
             self.e.step_all(dt)
             self.count += 1
             return
         if getattr(self.e, "edge_first", False):
             if not self.primed:               # ghosts of the initial state, once
-                self._exchange_blocking()
+                self._finish(self.exchange_start())
                 self.primed = True
             for stage in range(2):
                 self.e.compute_edges(stage, dt)
-                reqs = self.exchange_start()
-                self.e.compute_interior(stage, dt)    # overlaps the exchange
-                for r in reqs:
-                    r.wait()
-                self.e.comm_end()
-                self.e.unpack(0)
-                self.e.unpack(1)
+                packed = self._pack()
+                if hasattr(self.e, "mark_packed"):
+                    self.e.mark_packed()              # the exchange will wait for the pack only
+                # the interior rows are queued BEFORE the exchange is posted: posting it costs
+                # host time, which the GPU then spends in the update kernel instead of idle
+                self.e.compute_interior(stage, dt)
+                self._finish(self.exchange_start(packed))
             return
         for phase in range(self.e.phases):
             reqs = self.exchange_start()
             self.e.compute_overlapped(phase, dt)      # overlaps the exchange
-            for r in reqs:
-                r.wait()
-            self.e.comm_end()
-            self.e.unpack(0)
-            self.e.unpack(1)
+            self._finish(reqs)
             self.e.compute_after(phase, dt)
-
-
-    def _exchange_blocking(self):
-        reqs = self.exchange_start()
-        for r in reqs:
-            r.wait()
-        self.e.comm_end()
-        self.e.unpack(0)
-        self.e.unpack(1)
 
     def run(self, nsteps, dt):
         """`nsteps` steps; with a deep halo the k local steps between two exchanges are one
@@ -129,12 +136,7 @@ class BandRunner:
             while done < nsteps:
                 left = self.k - self.count % self.k
                 if left == self.k:
-                    reqs = self.exchange_start()
-                    for r in reqs:
-                        r.wait()
-                    self.e.comm_end()
-                    self.e.unpack(0)
-                    self.e.unpack(1)
+                    self._finish(self.exchange_start())
                 n = min(left, nsteps - done)
                 self.e.step_n(n, dt)
                 self.count += n
@@ -166,6 +168,8 @@ class HipBandEngine:
         self.comm = torch.cuda.Stream() if overlap else self.compute
         self.overlap = overlap
         self._ctx = None
+        self._packed = torch.cuda.Event()
+        self._wait_packed = False
 
     def _s(self, stream):
         return stream.cuda_stream
@@ -176,6 +180,20 @@ class HipBandEngine:
             self.compute.synchronize()
         return self.sbuf[side]
 
+    def pack_both(self):
+        self.c.halo_pack2(self.sbuf[0].data_ptr(), self.sbuf[1].data_ptr(), self._s(self.compute))
+        if not self.stream_aware:
+            self.compute.synchronize()
+        return self.sbuf[0], self.sbuf[1]
+
+    def unpack_both(self):
+        self.c.halo_unpack2(self.rbuf[0].data_ptr(), self.rbuf[1].data_ptr(), self._s(self.compute))
+
+    def mark_packed(self):
+        if self.overlap:
+            self._packed.record(self.compute)
+            self._wait_packed = True
+
     def recv_buffer(self, side):
         return self.rbuf[side]
 
@@ -185,7 +203,11 @@ class HipBandEngine:
         # is launched next on the compute stream runs concurrently with the exchange
         if not self.overlap:
             return
-        self.comm.wait_stream(self.compute)
+        if self._wait_packed:               # work queued on the compute stream after the pack
+            self.comm.wait_event(self._packed)      # (the interior rows) is not waited for
+            self._wait_packed = False
+        else:
+            self.comm.wait_stream(self.compute)
         self._ctx = self.torch.cuda.stream(self.comm)
         self._ctx.__enter__()
 

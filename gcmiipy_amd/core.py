@@ -199,6 +199,12 @@ class Core:
     def halo_unpack(self, side, dev_ptr, stream=None):
         _check(lib.gcm_halo_unpack(self._h, side, dev_ptr, stream), self._h)
 
+    def halo_pack2(self, north_ptr, south_ptr, stream=None):
+        _check(lib.gcm_halo_pack2(self._h, north_ptr, south_ptr, stream), self._h)
+
+    def halo_unpack2(self, north_ptr, south_ptr, stream=None):
+        _check(lib.gcm_halo_unpack2(self._h, north_ptr, south_ptr, stream), self._h)
+
     def step_interior(self, dt, stream=None):
         _check(lib.gcm_step_interior(self._h, float(dt), stream), self._h)
 

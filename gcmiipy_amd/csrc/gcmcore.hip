@@ -490,44 +490,59 @@ size_t gcm_halo_bytes(const gcm_handle *h) {
     return (size_t)nf * h->G * h->W * sizeof(double);
 }
 
-// side 0: rows [0, 2) -> buffer (they become the north neighbour's south ghost rows)
-// side 1: rows [H-2, H) -> buffer
-int gcm_halo_pack(gcm_handle *h, int side, void *dev_buf, void *stream) {
-    if (!h || !dev_buf || (side != 0 && side != 1)) return GCM_ERR_ARG;
-    if (h->pe) return pe25d_halo(h->pe, true, side, dev_buf, (hipStream_t)stream, &h->err);
+}  // extern "C"
+
+// side 0: rows [0, G) <-> buffer (pack: they become the north neighbour's south ghost rows;
+// unpack: buffer -> ghost rows [-G, 0)); side 1: rows [H-G, H) / ghost rows [H, H+G)
+static int halo_segments(gcm_handle *h, bool pack, int side, void *dev_buf, SegCopy *c) {
+    if (h->pe) return pe25d_halo_segments(h->pe, pack, side, dev_buf, c, &h->err);
     double *b = (double *)dev_buf;
     const size_t n = (size_t)h->G * h->W;
-    SegCopy c{};
     for (int f = 0; f < GCM_NFIELDS; ++f) {
         if (!h->has[f]) continue;
-        c.src[c.nseg] = side == 0 ? h->cur[f] : h->cur[f] + (size_t)(h->H - h->G) * h->W;
-        c.dst[c.nseg] = b;
-        c.n[c.nseg++] = (long)n;
+        double *edge = side == 0 ? h->cur[f] : h->cur[f] + (size_t)(h->H - h->G) * h->W;
+        double *ghost = side == 0 ? h->cur[f] - n : h->cur[f] + (size_t)h->H * h->W;
+        c->src[c->nseg] = pack ? edge : b;
+        c->dst[c->nseg] = pack ? b : ghost;
+        c->n[c->nseg++] = (long)n;
         b += n;
     }
+    return GCM_OK;
+}
+
+static int halo_run(gcm_handle *h, bool pack, void *north, void *south, void *stream) {
+    SegCopy c{};
+    int rc = GCM_OK;
+    if (north) rc = halo_segments(h, pack, 0, north, &c);
+    if (rc == GCM_OK && south) rc = halo_segments(h, pack, 1, south, &c);
+    if (rc != GCM_OK) return rc;
+    if (!pack && !h->pe) h->since_exchange = 0;
     launch_seg_copy(c, (hipStream_t)stream);
     HIPCHK(h, hipGetLastError());
     return GCM_OK;
 }
 
-// side 0: buffer -> ghost rows [-2, 0); side 1: buffer -> ghost rows [H, H+2)
+extern "C" {
+
+int gcm_halo_pack(gcm_handle *h, int side, void *dev_buf, void *stream) {
+    if (!h || !dev_buf || (side != 0 && side != 1)) return GCM_ERR_ARG;
+    return halo_run(h, true, side == 0 ? dev_buf : nullptr, side == 1 ? dev_buf : nullptr, stream);
+}
+
 int gcm_halo_unpack(gcm_handle *h, int side, const void *dev_buf, void *stream) {
     if (!h || !dev_buf || (side != 0 && side != 1)) return GCM_ERR_ARG;
-    if (h->pe) return pe25d_halo(h->pe, false, side, (void *)dev_buf, (hipStream_t)stream, &h->err);
-    const double *b = (const double *)dev_buf;
-    const size_t n = (size_t)h->G * h->W;
-    h->since_exchange = 0;
-    SegCopy c{};
-    for (int f = 0; f < GCM_NFIELDS; ++f) {
-        if (!h->has[f]) continue;
-        c.dst[c.nseg] = side == 0 ? h->cur[f] - n : h->cur[f] + (size_t)h->H * h->W;
-        c.src[c.nseg] = b;
-        c.n[c.nseg++] = (long)n;
-        b += n;
-    }
-    launch_seg_copy(c, (hipStream_t)stream);
-    HIPCHK(h, hipGetLastError());
-    return GCM_OK;
+    return halo_run(h, false, side == 0 ? (void *)dev_buf : nullptr, side == 1 ? (void *)dev_buf : nullptr, stream);
+}
+
+// both sides in one launch
+int gcm_halo_pack2(gcm_handle *h, void *north_buf, void *south_buf, void *stream) {
+    if (!h || !north_buf || !south_buf) return GCM_ERR_ARG;
+    return halo_run(h, true, north_buf, south_buf, stream);
+}
+
+int gcm_halo_unpack2(gcm_handle *h, const void *north_buf, const void *south_buf, void *stream) {
+    if (!h || !north_buf || !south_buf) return GCM_ERR_ARG;
+    return halo_run(h, false, (void *)north_buf, (void *)south_buf, stream);
 }
 
 int gcm_sync(gcm_handle *h) {

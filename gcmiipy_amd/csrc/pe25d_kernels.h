@@ -11,6 +11,7 @@
 namespace gcm {
 
 struct Pe25d;
+struct SegCopy;   // sw2d_kernels.h
 
 Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t s, std::string *err);
 void pe25d_destroy(Pe25d *m);
@@ -23,7 +24,7 @@ int pe25d_step_part(Pe25d *m, int part, double dt, hipStream_t s, std::string *e
 int pe25d_step_phase(Pe25d *m, int phase, double dt, hipStream_t s, std::string *err);
 int pe25d_half(Pe25d *m, int stage, double dt, hipStream_t s, std::string *err);
 size_t pe25d_halo_bytes(const Pe25d *m);
-int pe25d_halo(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s, std::string *err);
+int pe25d_halo_segments(Pe25d *m, bool pack, int side, void *dev_buf, SegCopy *c, std::string *err);
 int pe25d_ground(Pe25d *m, bool set, const double *in, double *out, std::string *err);
 int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, double t_sw, double albedo,
                     const double *lat, const double *lon, double *dTdt_host, double *dtg_host,

@@ -495,6 +495,7 @@ __global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
     T ex_k = exner(spc * a.sig[0] + a.ptop, tab);
     const T t0 = t_k, ex0 = ex_k;                       // level 0, for the k wrap at the top
     T acc = T(0.0);
+#pragma unroll 6
     for (int k = 0; k < L; ++k) {
         const long o = c3 + (long)k * W + i;
         const T tp = spc * a.sig[k] + a.ptop;
@@ -561,6 +562,7 @@ __global__ __launch_bounds__(256) void pe_pit_kernel(PeArgsT<T> a) {
         T rc = T(0.0);
         int s = a.nseg - 2;
         int stop = seg_lo(s + 1, a.nseg, L);
+#pragma unroll 4
         for (int k = L - 1; k >= 1 && s >= 0; --k) {
             const long o = c3 + (long)k * W;
             rc = conv_acc(rc, a.spu[o + i], a.spu[o + iw], inv_dxj, a.sv[o + i], jph_c, a.sv[n3 + (long)k * W + i], jph_n,
@@ -1353,6 +1355,7 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         // two independent chains: K1 -> K2b (mass flux, pit) on the caller's stream, K2a -> K3
         // (geopotential, filtered pressure-gradient force) on the handle's second stream.  The FFT
         // kernels are latency bound and the column kernels bandwidth bound, so they share the chip.
+        // (Which chain sits on which stream makes no difference: they take about equally long.)
         hipStream_t s2 = m->aux ? m->aux : s;
         if (m->aux) {
             (void)hipEventRecord(m->ev_fork, s);
@@ -1517,7 +1520,7 @@ size_t pe25d_halo_bytes(const Pe25d *m) {
 }
 
 template <typename T>
-static void halo_t(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s) {
+static void halo_t(Pe25d *m, bool pack, int side, void *dev_buf, SegCopy *c) {
     PeBufs<T> &Bf = bufs<T>(m);
     // unpack: ghosts of the predicted state once it exists, else of the current state;
     // pack: the same, unless a step_phase call named the set whose edge rows were just produced
@@ -1525,7 +1528,6 @@ static void halo_t(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s) 
     if (pack && m->pack_set >= 0) set = m->pack_set;
     if (!pack && m->pack_set >= 0 && m->pack_set != 2) set = m->pack_set;   // new-state ghosts arrive before the swap
     T *b = (T *)dev_buf;
-    SegCopy c{};
     for (int f = 0; f < GCM_NFIELDS; ++f) {
         const size_t per_row = (size_t)m->W * (f == GCM_P ? 1 : m->L);
         const long n = (long)(kGhost * per_row);
@@ -1533,25 +1535,21 @@ static void halo_t(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s) 
         T *edge = side == 0 ? base : base + (size_t)(m->H - kGhost) * per_row;
         T *ghost = side == 0 ? base - (size_t)kGhost * per_row : base + (size_t)m->H * per_row;
         // SegCopy moves 8-byte words: 2 rows x (even W) floats is a whole number of them
-        c.src[c.nseg] = (const double *)(pack ? edge : b);
-        c.dst[c.nseg] = (double *)(pack ? b : ghost);
-        c.n[c.nseg++] = n * (long)sizeof(T) / 8;
+        c->src[c->nseg] = (const double *)(pack ? edge : b);
+        c->dst[c->nseg] = (double *)(pack ? b : ghost);
+        c->n[c->nseg++] = n * (long)sizeof(T) / 8;
         b += n;
     }
-    launch_seg_copy(c, s);
 }
 
-int pe25d_halo(Pe25d *m, bool pack, int side, void *dev_buf, hipStream_t s, std::string *err) {
+// appends the copies of one side to *c (the caller launches them: one side or both in one launch)
+int pe25d_halo_segments(Pe25d *m, bool pack, int side, void *dev_buf, SegCopy *c, std::string *err) {
     if (m->f32 && (m->W % 2)) {
         *err = "pe25d halo: fp32 bands need an even width";
         return GCM_ERR_UNSUPPORTED;
     }
-    if (m->f32) halo_t<float>(m, pack, side, dev_buf, s);
-    else halo_t<double>(m, pack, side, dev_buf, s);
-    if (hipGetLastError() != hipSuccess) {
-        *err = "hip: pe25d halo copy launch failed";
-        return GCM_ERR_HIP;
-    }
+    if (m->f32) halo_t<float>(m, pack, side, dev_buf, c);
+    else halo_t<double>(m, pack, side, dev_buf, c);
     return GCM_OK;
 }
 

@@ -185,6 +185,9 @@ int gcm_solar_step(gcm_handle *h, double dt, double utc, double t_lw, double t_s
 size_t gcm_halo_bytes(const gcm_handle *h);
 int gcm_halo_pack(gcm_handle *h, int side, void *dev_buf, void *stream);
 int gcm_halo_unpack(gcm_handle *h, int side, const void *dev_buf, void *stream);
+/* both sides with one launch (buffers as above: north = side 0, south = side 1) */
+int gcm_halo_pack2(gcm_handle *h, void *north_buf, void *south_buf, void *stream);
+int gcm_halo_unpack2(gcm_handle *h, const void *north_buf, const void *south_buf, void *stream);
 /* Step split for comm/compute overlap: rows that need no ghost data, then the rest. */
 int gcm_step_interior(gcm_handle *h, double dt, void *stream);
 int gcm_step_boundary(gcm_handle *h, double dt, void *stream);
