@@ -92,6 +92,17 @@ class BandRunner:
                           d.P2POp(d.irecv, rs, self.south), d.P2POp(d.irecv, rn, self.north)])
         return d.batch_isend_irecv(self._ops[1])
 
+    def begin_stage(self, stage, dt):
+        """edge-first Euler stage up to the posted exchange -> requests for _finish()"""
+        self.e.compute_edges(stage, dt)
+        packed = self._pack()
+        if hasattr(self.e, "mark_packed"):
+            self.e.mark_packed()              # the exchange will wait for the pack only
+        # the interior rows are queued BEFORE the exchange is posted: posting it costs
+        # host time, which the GPU then spends in the update kernel instead of idle
+        self.e.compute_interior(stage, dt)
+        return self.exchange_start(packed)
+
     def _finish(self, reqs):
         for r in reqs:
             r.wait()
@@ -113,14 +124,7 @@ class BandRunner:
                 self._finish(self.exchange_start())
                 self.primed = True
             for stage in range(2):
-                self.e.compute_edges(stage, dt)
-                packed = self._pack()
-                if hasattr(self.e, "mark_packed"):
-                    self.e.mark_packed()              # the exchange will wait for the pack only
-                # the interior rows are queued BEFORE the exchange is posted: posting it costs
-                # host time, which the GPU then spends in the update kernel instead of idle
-                self.e.compute_interior(stage, dt)
-                self._finish(self.exchange_start(packed))
+                self._finish(self.begin_stage(stage, dt))
             return
         for phase in range(self.e.phases):
             reqs = self.exchange_start()
@@ -170,6 +174,12 @@ class HipBandEngine:
         self._ctx = None
         self._packed = torch.cuda.Event()
         self._wait_packed = False
+        # GCM_PE25D: the library updates and packs the edge rows on its second stream while the
+        # interior rows run on the compute stream (gcm_set_halo_buffers / gcm_wait_edges)
+        self.async_edges = self.edge_first
+        self._edges_pending = False
+        if self.async_edges:
+            core.set_halo_buffers(self.sbuf[0].data_ptr(), self.sbuf[1].data_ptr())
 
     def _s(self, stream):
         return stream.cuda_stream
@@ -181,6 +191,8 @@ class HipBandEngine:
         return self.sbuf[side]
 
     def pack_both(self):
+        if self._edges_pending:             # packed by the library inside compute_edges()
+            return self.sbuf[0], self.sbuf[1]
         self.c.halo_pack2(self.sbuf[0].data_ptr(), self.sbuf[1].data_ptr(), self._s(self.compute))
         if not self.stream_aware:
             self.compute.synchronize()
@@ -190,7 +202,7 @@ class HipBandEngine:
         self.c.halo_unpack2(self.rbuf[0].data_ptr(), self.rbuf[1].data_ptr(), self._s(self.compute))
 
     def mark_packed(self):
-        if self.overlap:
+        if self.overlap and not self._edges_pending:
             self._packed.record(self.compute)
             self._wait_packed = True
 
@@ -201,6 +213,15 @@ class HipBandEngine:
         # the collective library orders its work after the *current* stream: make that
         # the comm stream, which waits for the pack kernels, so the interior step that
         # is launched next on the compute stream runs concurrently with the exchange
+        if self._edges_pending:             # the send waits for the library's edge-row pack only
+            self._edges_pending = False
+            self.c.wait_edges(self._s(self.comm))
+            if not self.stream_aware:
+                self.comm.synchronize()
+            if self.overlap:
+                self._ctx = self.torch.cuda.stream(self.comm)
+                self._ctx.__enter__()
+            return
         if not self.overlap:
             return
         if self._wait_packed:               # work queued on the compute stream after the pack
@@ -241,6 +262,7 @@ class HipBandEngine:
     # GCM_PE25D edge-first protocol (gcm_step_phase)
     def compute_edges(self, stage, dt):
         self.c.step_phase(2 * stage, dt, self._s(self.compute))
+        self._edges_pending = self.async_edges
 
     def compute_interior(self, stage, dt):
         self._leave_comm()

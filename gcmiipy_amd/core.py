@@ -205,6 +205,12 @@ class Core:
     def halo_unpack2(self, north_ptr, south_ptr, stream=None):
         _check(lib.gcm_halo_unpack2(self._h, north_ptr, south_ptr, stream), self._h)
 
+    def set_halo_buffers(self, north_ptr, south_ptr):
+        _check(lib.gcm_set_halo_buffers(self._h, north_ptr, south_ptr), self._h)
+
+    def wait_edges(self, stream):
+        _check(lib.gcm_wait_edges(self._h, stream), self._h)
+
     def step_interior(self, dt, stream=None):
         _check(lib.gcm_step_interior(self._h, float(dt), stream), self._h)
 

@@ -463,6 +463,18 @@ int gcm_step_phase(gcm_handle *h, int phase, double dt, void *stream) {
     return pe25d_step_phase(h->pe, phase, dt, (hipStream_t)stream, &h->err);
 }
 
+int gcm_set_halo_buffers(gcm_handle *h, void *north_send, void *south_send) {
+    if (!h) return GCM_ERR_ARG;
+    if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_set_halo_buffers: GCM_PE25D latitude bands only");
+    return pe25d_set_halo_buffers(h->pe, north_send, south_send, &h->err);
+}
+
+int gcm_wait_edges(gcm_handle *h, void *stream) {
+    if (!h) return GCM_ERR_ARG;
+    if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_wait_edges: GCM_PE25D latitude bands only");
+    return pe25d_wait_edges(h->pe, (hipStream_t)stream, &h->err);
+}
+
 int gcm_half_step(gcm_handle *h, int stage, double dt) {
     if (!h || (stage != 0 && stage != 1)) return GCM_ERR_ARG;
     if (h->pe) return pe25d_half(h->pe, stage, dt, h->stream, &h->err);

@@ -982,6 +982,11 @@ struct Pe25d {
     size_t *ev_used = nullptr;
     hipStream_t aux = nullptr;                  // second stream of a stage (K2a -> K3), see half_t
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // latitude band with registered send buffers: the edge rows of a stage are updated and packed
+    // on `aux` while the interior rows run on the caller's stream (pe25d_step_phase)
+    void *send_buf[2] = {nullptr, nullptr};
+    hipEvent_t ev_a = nullptr, ev_edges = nullptr;
+    bool edges_pending = false;
 };
 
 template <typename T> static PeBufs<T> &bufs(Pe25d *m);
@@ -1231,12 +1236,15 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
     build_exner_table(tab);
     if (!dev_upload(m, &m->exner_tab, tab, kExnerTabDoubles)) return bad("exner table");
     const char *no_aux = getenv("GCM_PE_SINGLE_STREAM");      // diagnostic: one chain, one stream
-    if (!(no_aux && no_aux[0] == '1')) {
-        if (hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess)
-            return bad("second stream");
-    }
+    // a plain stream: a high-priority one finished the edge rows earlier, but in some processes
+    // (depending on how many streams existed before) the whole step then ran at half speed
+    if (!(no_aux && no_aux[0] == '1') && hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking) != hipSuccess)
+        return bad("second stream");
+    if (hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_edges, hipEventDisableTiming) != hipSuccess)
+        return bad("events");
     return m;
 }
 
@@ -1244,6 +1252,8 @@ void pe25d_destroy(Pe25d *m) {
     if (!m) return;
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->ev_a) (void)hipEventDestroy(m->ev_a);
+    if (m->ev_edges) (void)hipEventDestroy(m->ev_edges);
     if (m->aux) (void)hipStreamDestroy(m->aux);
     for (void *p : m->allocs) (void)hipFree(p);
     delete m;
@@ -1335,6 +1345,8 @@ static PeArgsT<T> make_args(Pe25d *m, int stage_set, int out_set, double dt) {
     return a;
 }
 
+static bool async_edges(const Pe25d *m) { return m->send_buf[0] && m->send_buf[1]; }
+
 static void tick(Pe25d *m, hipStream_t s) {
     if (m->ev && m->ev_used && *m->ev_used < m->ev->size()) (void)hipEventRecord((*m->ev)[(*m->ev_used)++], s);
 }
@@ -1373,6 +1385,7 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
             const long tiles = (long)((W + 255) / 256) * (a.j1 - a.j0);
             hipLaunchKernelGGL(pe_pit_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, s, a);
         }
+        if (mode == 1 && async_edges(m) && m->aux) (void)hipEventRecord(m->ev_a, s);
         a.j1 = j1;
         hipLaunchKernelGGL(pgf_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, s2, a);
         if (m->aux) {
@@ -1380,7 +1393,7 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
             (void)hipStreamWaitEvent(s, m->ev_join, 0);
         }
     }
-    auto update_rows = [&](int r0, int r1, int rb0, int rb1) {     // rows [r0, r1) and [rb0, rb1), one launch
+    auto update_rows = [&](int r0, int r1, int rb0, int rb1, hipStream_t st) {   // rows [r0, r1) and [rb0, rb1), one launch
         const int rows = std::max(0, r1 - r0) + std::max(0, rb1 - rb0);
         if (rows <= 0) return;
         a.j0 = r0;
@@ -1388,19 +1401,37 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         a.jb0 = rb0;
         a.jb1 = std::max(rb0, rb1);
         const long tiles = (long)((W + 255) / 256) * rows * a.nseg;
-        hipLaunchKernelGGL(pe_update_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(pe_update_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, st, a);
     };
     const bool split = mode != 0 && (j1 - j0) > 2 * kGhost;
-    if (mode == 0 || !split) {
-        if (mode != 2) {      // an unsplittable (tiny) band does all of K4 in mode 1
-            tick(m, s);
-            update_rows(j0, j1, 0, 0);
-            tick(m, s);
-        }
+    if (mode == 0) {
+        tick(m, s);
+        update_rows(j0, j1, 0, 0, s);
+        tick(m, s);
     } else if (mode == 1) {
-        update_rows(j0, j0 + kGhost, j1 - kGhost, j1);
+        // the rows the neighbours wait for (an unsplittable, tiny band: all of them).  With send
+        // buffers registered they are updated and packed on the second stream, which has the
+        // K2a -> K3 chain already and waits for K1 -> K2b here; the caller's stream goes straight
+        // on to the interior rows (mode 2), so the two launches share the chip.
+        const bool as = async_edges(m);
+        hipStream_t se = as && m->aux ? m->aux : s;
+        if (as && m->aux) (void)hipStreamWaitEvent(m->aux, m->ev_a, 0);
+        if (split) update_rows(j0, j0 + kGhost, j1 - kGhost, j1, se);
+        else update_rows(j0, j1, 0, 0, se);
+        if (as) {
+            SegCopy c{};
+            std::string err;
+            (void)pe25d_halo_segments(m, true, 0, m->send_buf[0], &c, &err);
+            (void)pe25d_halo_segments(m, true, 1, m->send_buf[1], &c, &err);
+            launch_seg_copy(c, se);
+            (void)hipEventRecord(m->ev_edges, se);
+            m->edges_pending = true;
+        }
     } else {
-        update_rows(j0 + kGhost, j1 - kGhost, 0, 0);
+        if (split) update_rows(j0 + kGhost, j1 - kGhost, 0, 0, s);
+        // whatever follows on the caller's stream also follows the edge rows
+        if (async_edges(m) && m->edges_pending) (void)hipStreamWaitEvent(s, m->ev_edges, 0);
+        m->edges_pending = false;
     }
 }
 
@@ -1485,16 +1516,16 @@ int pe25d_step_phase(Pe25d *m, int phase, double dt, hipStream_t s, std::string 
     }
     switch (phase) {
         case 0:
-            half(m, m->cur_i, 2, dt, 0, m->H, s, 1);
             m->star_valid = true;
             m->pack_set = 2;
+            half(m, m->cur_i, 2, dt, 0, m->H, s, 1);
             break;
         case 1:
             half(m, m->cur_i, 2, dt, 0, m->H, s, 2);
             break;
         case 2:
-            half(m, 2, 1 - m->cur_i, dt, 0, m->H, s, 1);
             m->pack_set = 1 - m->cur_i;
+            half(m, 2, 1 - m->cur_i, dt, 0, m->H, s, 1);
             break;
         case 3:
             half(m, 2, 1 - m->cur_i, dt, 0, m->H, s, 2);
@@ -1508,6 +1539,34 @@ int pe25d_step_phase(Pe25d *m, int phase, double dt, hipStream_t s, std::string 
     }
     if (hipGetLastError() != hipSuccess) {
         *err = "hip: pe25d kernel launch failed";
+        return GCM_ERR_HIP;
+    }
+    return GCM_OK;
+}
+
+int pe25d_set_halo_buffers(Pe25d *m, void *north, void *south, std::string *err) {
+    if (m->wrap) {
+        *err = "set_halo_buffers: handle is not a latitude band";
+        return GCM_ERR_STATE;
+    }
+    if ((north == nullptr) != (south == nullptr)) {
+        *err = "set_halo_buffers: give both buffers, or neither to unregister";
+        return GCM_ERR_ARG;
+    }
+    (void)hipDeviceSynchronize();
+    m->send_buf[0] = north;
+    m->send_buf[1] = south;
+    m->edges_pending = false;
+    return GCM_OK;
+}
+
+int pe25d_wait_edges(Pe25d *m, hipStream_t s, std::string *err) {
+    if (!async_edges(m)) {
+        *err = "wait_edges: no send buffers registered (gcm_set_halo_buffers)";
+        return GCM_ERR_STATE;
+    }
+    if (hipStreamWaitEvent(s, m->ev_edges, 0) != hipSuccess) {
+        *err = "hip: wait_edges failed";
         return GCM_ERR_HIP;
     }
     return GCM_OK;

@@ -200,6 +200,13 @@ int gcm_step_boundary(gcm_handle *h, double dt, void *stream);
  * next step's phase 0 needs).  Before the first step the current state's ghosts must be exchanged
  * once (pack / unpack with no phase pending).                                                    */
 int gcm_step_phase(gcm_handle *h, int phase, double dt, void *stream);
+/* Optional: register the two DEVICE send buffers (gcm_halo_bytes each).  Phase 0 / 2 then update the
+ * edge rows AND pack them into these buffers on the handle's second stream, concurrently with
+ * whatever the caller queues next on `stream` (phase 1 / 3, the interior rows); no gcm_halo_pack
+ * call is needed for those phases.  gcm_wait_edges makes a stream (the one the send is posted on)
+ * wait for that pack.  NULL, NULL unregisters.                                                  */
+int gcm_set_halo_buffers(gcm_handle *h, void *north_send, void *south_send);
+int gcm_wait_edges(gcm_handle *h, void *stream);
 
 int gcm_sync(gcm_handle *h);
 

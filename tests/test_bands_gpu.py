@@ -201,6 +201,98 @@ def test_bands_in_process_pe25d_edge_first(nb):
         assert rel_err(got, want[f]) < 1e-13, (k, rel_err(got, want[f]))
 
 
+class _Ring:
+    """torch.distributed stand-in for several band engines in ONE process: a posted exchange is
+    carried out, stream-ordered and without any host synchronisation, when its requests are waited
+    for -- by then every rank has posted.  A receive waits (GPU side) for the sender's post event,
+    i.e. for the sender's comm stream at the point where its send buffers are valid."""
+    isend, irecv = "isend", "irecv"
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    def __init__(self, torch, hub, rank):
+        self.torch, self.hub, self.rank = torch, hub, rank
+
+    def batch_isend_irecv(self, ops):
+        stream = self.torch.cuda.current_stream()
+        ev = self.torch.cuda.Event()
+        ev.record(stream)
+        self.hub[self.rank] = (ops, ev, stream)
+        ring = self
+
+        class Req:
+            def wait(self):
+                ops_, _, stream_ = ring.hub[ring.rank]
+                recvs = [o for o in ops_ if o.op == "irecv"]
+                with ring.torch.cuda.stream(stream_):
+                    for n, o in enumerate(recvs):          # n-th receive <- the peer's n-th send
+                        pops, pev, _ = ring.hub[o.peer]
+                        sends = [q for q in pops if q.op == "isend" and q.peer == ring.rank]
+                        src = sends[n] if len(sends) > 1 else sends[0]
+                        stream_.wait_event(pev)
+                        o.tensor.copy_(src.tensor, non_blocking=True)
+                    done = ring.torch.cuda.Event()
+                    done.record(stream_)
+                    ring.hub.setdefault("done", []).append(done)   # = the peers' sends completed
+        return [Req()]
+
+
+@pytest.mark.parametrize("nb", [2, 3, 4])
+def test_band_runners_in_process_stream_ordered(nb):
+    """BandRunner + HipBandEngine for GCM_PE25D, every band on its own compute and comm stream,
+    exchange = stream-ordered device copies: no host synchronisation anywhere inside the steps,
+    so a missing stream dependency (edge rows updated and packed on the library's second stream
+    while the interior rows run) shows up as wrong numbers.  Bit-identical to the single band."""
+    import torch
+    import gcmiipy_amd as g
+    from gcmiipy_amd import geometry
+    from gcmiipy_amd.bands import BandRunner, HipBandEngine, split_rows
+    H, W, L, steps = 23, 36, 9, 4
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    ic = _ic_pe(geom)
+    ref = g.Core(g._lib.PE25D, W, H, L, geom=geom)
+    ref.set_state(*ic)
+    ref.step(steps, 120.0)
+    want = ref.get_state()
+    ref.close()
+    hub, runners, cores = {}, [], []
+    for r, (row0, n) in enumerate(split_rows(H, nb)):
+        c = g.Core(g._lib.PE25D, W, n, L, geom=geom, nranks=nb, rank=r, global_height=H, row0=row0)
+        sl = slice(row0, row0 + n)
+        c.set_state(ic[0][sl], *[a[:, sl] for a in ic[1:]])
+        with torch.cuda.stream(torch.cuda.Stream()):
+            eng = HipBandEngine(c, torch)
+        assert eng.edge_first and eng.async_edges
+        runners.append(BandRunner(eng, r, nb, _Ring(torch, hub, r)))
+        cores.append(c)
+
+    def all_ranks(post):
+        posted = []
+        for rn in runners:
+            posted.append(post(rn))
+            rn.e._leave_comm()              # several engines in one thread: do not nest stream contexts
+        for rn, reqs in zip(runners, posted):
+            rn._finish(reqs)
+        for rn in runners:                  # a send buffer is reused only after its send completed
+            for ev in hub.get("done", []):
+                rn.e.compute.wait_event(ev)
+        hub["done"] = []
+
+    all_ranks(lambda rn: rn.exchange_start())            # ghosts of the initial state
+    for _ in range(steps):
+        for stage in (0, 1):
+            all_ranks(lambda rn: rn.begin_stage(stage, 120.0))
+    torch.cuda.synchronize()
+    parts = [c.get_state() for c in cores]
+    for c in cores:
+        c.close()
+    for f, k in enumerate("puvtq"):
+        got = np.concatenate([p_[f] for p_ in parts], axis=0 if f == 0 else 1)
+        assert np.array_equal(got, want[f]), (k, rel_err(got, want[f]))
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
