@@ -22,34 +22,13 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "fft_lds.h"
 #include "gcm_math.h"
 #include "sw2d_kernels.h"
 
 namespace gcm {
 
-constexpr int kMaxRadices = 24;
-
-struct FftPlan {
-    int n, nrad;
-    int rad[kMaxRadices];
-    unsigned magic[kMaxRadices];   // ceil(2^32 / Ns) per pass: b / Ns == umulhi(b, magic) for b*Ns < 2^32
-};
-
 constexpr int kMaxSeg = 4;      // level segments of the update kernel (short bands)
-constexpr int kMaxSuper = 8;
-struct SuperPlan {
-    int ok;                        // 0: use the generic ping-pong path
-    int npass, threads, maxr;      // workgroup size = widest pass rounded up to whole waves
-    int r1[kMaxSuper], r2[kMaxSuper];
-    unsigned magic[kMaxSuper];     // ceil(2^32 / Ns) of the pass
-};
-
-template <typename T> struct Vec2;
-template <> struct Vec2<double> { using type = double2; };
-template <> struct Vec2<float> { using type = float2; };
-template <typename V> using Sc = decltype(V().x);                    // scalar type of a 2-vector
-template <typename V> __device__ __forceinline__ V mkv(Sc<V> a, Sc<V> b) { V r; r.x = a; r.y = b; return r; }
-
 // real-type specific pieces: reciprocal and (p/P0)**kappa (fp32: v_rcp_f32 is 1 ulp; powf)
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float exner(float p, const double *) { return __powf(p * 1e-5f, (float)kKappa); }
@@ -97,310 +76,6 @@ struct Idx {
     __device__ __forceinline__ long r2(int j) const { return (long)jr(j) * W; }
 };
 
-// ---------------------------------------------------------------- FFT in LDS
-// Stockham autosort, mixed radix.  x -> result returned in x or y (pointer returned).
-template <typename V>
-__device__ __forceinline__ V cmul(V a, V b) {
-    return mkv<V>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-
-template <typename V>
-__device__ __forceinline__ V cadd(V a, V b) { return mkv<V>(a.x + b.x, a.y + b.y); }
-template <typename V>
-__device__ __forceinline__ V csub(V a, V b) { return mkv<V>(a.x - b.x, a.y - b.y); }
-// -i z (forward transforms) or +i z (inverse)
-template <bool INV, typename V>
-__device__ __forceinline__ V rot(V z) {
-    return INV ? mkv<V>(-z.y, z.x) : mkv<V>(z.y, -z.x);
-}
-template <bool INV, typename V>
-__device__ __forceinline__ V twid(const V *tw, int idx) {
-    V w = tw[idx];
-    if (INV) w.y = -w.y;
-    return w;
-}
-
-template <bool INV, typename V>
-__device__ V *fft_lds(V *x, V *y, const V *tw, const FftPlan &P) {
-    using T = Sc<V>;
-    const int N = P.n;
-    int Ns = 1;
-    for (int pass = 0; pass < P.nrad; ++pass) {
-        const int r = P.rad[pass];
-        const int nb = N / r;
-        const int tstep = N / (Ns * r);  // twiddle index step
-        const unsigned magic = P.magic[pass];
-        for (int b = threadIdx.x; b < nb; b += blockDim.x) {
-            const int blk = Ns == 1 ? b : (int)__umulhi((unsigned)b, magic);
-            const int k = b - blk * Ns;
-            const int j0 = blk * Ns * r + k;
-            const int t1 = k * tstep;
-            if (r == 2) {
-                const V a0 = x[b], a1 = cmul(x[b + nb], twid<INV>(tw, t1));
-                y[j0] = cadd(a0, a1);
-                y[j0 + Ns] = csub(a0, a1);
-            } else if (r == 4) {
-                const V a0 = x[b];
-                const V a1 = cmul(x[b + nb], twid<INV>(tw, t1));
-                const V a2 = cmul(x[b + 2 * nb], twid<INV>(tw, 2 * t1));
-                const V a3 = cmul(x[b + 3 * nb], twid<INV>(tw, 3 * t1));
-                const V s02 = cadd(a0, a2), d02 = csub(a0, a2);
-                const V s13 = cadd(a1, a3), jd = rot<INV>(csub(a1, a3));
-                y[j0] = cadd(s02, s13);
-                y[j0 + Ns] = cadd(d02, jd);
-                y[j0 + 2 * Ns] = csub(s02, s13);
-                y[j0 + 3 * Ns] = csub(d02, jd);
-            } else if (r == 3) {
-                const V a0 = x[b];
-                const V a1 = cmul(x[b + nb], twid<INV>(tw, t1));
-                const V a2 = cmul(x[b + 2 * nb], twid<INV>(tw, 2 * t1));
-                const V t = cadd(a1, a2);
-                const V m = mkv<V>(a0.x - T(0.5) * t.x, a0.y - T(0.5) * t.y);
-                V sv = rot<INV>(csub(a1, a2));
-                sv.x *= T(0.86602540378443864676);  // sin(2 pi / 3)
-                sv.y *= T(0.86602540378443864676);
-                y[j0] = cadd(a0, t);
-                y[j0 + Ns] = cadd(m, sv);
-                y[j0 + 2 * Ns] = csub(m, sv);
-            } else if (r == 5) {
-                constexpr T c1 = T(0.30901699437494742410), c2 = -T(0.80901699437494742410);
-                constexpr T s1 = T(0.95105651629515357212), s2 = T(0.58778525229247312917);
-                const V a0 = x[b];
-                const V a1 = cmul(x[b + nb], twid<INV>(tw, t1));
-                const V a2 = cmul(x[b + 2 * nb], twid<INV>(tw, 2 * t1));
-                const V a3 = cmul(x[b + 3 * nb], twid<INV>(tw, 3 * t1));
-                const V a4 = cmul(x[b + 4 * nb], twid<INV>(tw, 4 * t1));
-                const V p1 = cadd(a1, a4), p2 = cadd(a2, a3), q1 = csub(a1, a4), q2 = csub(a2, a3);
-                const V m1 = mkv<V>(a0.x + c1 * p1.x + c2 * p2.x, a0.y + c1 * p1.y + c2 * p2.y);
-                const V m2 = mkv<V>(a0.x + c2 * p1.x + c1 * p2.x, a0.y + c2 * p1.y + c1 * p2.y);
-                const V n1 = rot<INV>(mkv<V>(s1 * q1.x + s2 * q2.x, s1 * q1.y + s2 * q2.y));
-                const V n2 = rot<INV>(mkv<V>(s2 * q1.x - s1 * q2.x, s2 * q1.y - s1 * q2.y));
-                y[j0] = cadd(a0, cadd(p1, p2));
-                y[j0 + Ns] = cadd(m1, n1);
-                y[j0 + 2 * Ns] = cadd(m2, n2);
-                y[j0 + 3 * Ns] = csub(m2, n2);
-                y[j0 + 4 * Ns] = csub(m1, n1);
-            } else {
-                // generic radix: out[q] = sum_m (x_m w^(m k)) W_r^(q m), W_r^t = tw[(t mod r) N/r]
-                const int rstep = N / r;
-                for (int qq = 0; qq < r; ++qq) {
-                    V acc = mkv<V>(T(0.0), T(0.0));
-                    for (int m = 0; m < r; ++m) {
-                        const V t = cmul(x[b + m * nb], twid<INV>(tw, (m * t1 + ((qq * m) % r) * rstep) % N));
-                        acc.x += t.x;
-                        acc.y += t.y;
-                    }
-                    y[j0 + qq * Ns] = acc;
-                }
-            }
-        }
-        __syncthreads();
-        V *tmp = x;
-        x = y;
-        y = tmp;
-        Ns *= r;
-    }
-    return x;
-}
-
-// ---- composite-radix in-place passes for {2,3,5}-smooth lengths (the product path).
-// A pass has radix R = R1 * R2 (R1, R2 in {2,3,4,5}, R2 may be 1): 1440 = 10.12.12 is three
-// passes per direction instead of six, each thread does ONE R-point butterfly per pass entirely in
-// registers (Cooley-Tukey split into R2 butterflies of radix R1, the W_R twiddles, R1 butterflies
-// of radix R2), and a workgroup has only as many threads as the widest pass has butterflies.
-// The first forward pass reads its inputs straight from global memory (a functor), the first
-// inverse pass applies the filter multiplier while it reads, the last inverse pass stores to
-// global memory: LDS holds one row of complex values and is touched once per pass.
-template <int R, bool INV, typename V>
-__device__ __forceinline__ void butterfly(V (&v)[R]) {
-    using T = Sc<V>;
-    if (R == 1) {
-    } else if (R == 2) {
-        const V a0 = v[0], a1 = v[1];
-        v[0] = cadd(a0, a1);
-        v[1] = csub(a0, a1);
-    } else if (R == 4) {
-        const V s02 = cadd(v[0], v[2]), d02 = csub(v[0], v[2]);
-        const V s13 = cadd(v[1], v[3]), jd = rot<INV>(csub(v[1], v[3]));
-        v[0] = cadd(s02, s13);
-        v[1] = cadd(d02, jd);
-        v[2] = csub(s02, s13);
-        v[3] = csub(d02, jd);
-    } else if (R == 3) {
-        const V t = cadd(v[1], v[2]);
-        const V m = mkv<V>(v[0].x - T(0.5) * t.x, v[0].y - T(0.5) * t.y);
-        V sv = rot<INV>(csub(v[1], v[2]));
-        sv.x *= T(0.86602540378443864676);
-        sv.y *= T(0.86602540378443864676);
-        v[0] = cadd(v[0], t);
-        v[1] = cadd(m, sv);
-        v[2] = csub(m, sv);
-    } else {   // R == 5
-        constexpr T c1 = T(0.30901699437494742410), c2 = -T(0.80901699437494742410);
-        constexpr T s1 = T(0.95105651629515357212), s2 = T(0.58778525229247312917);
-        const V a0 = v[0];
-        const V p1 = cadd(v[1], v[4]), p2 = cadd(v[2], v[3]), q1 = csub(v[1], v[4]), q2 = csub(v[2], v[3]);
-        const V m1 = mkv<V>(a0.x + c1 * p1.x + c2 * p2.x, a0.y + c1 * p1.y + c2 * p2.y);
-        const V m2 = mkv<V>(a0.x + c2 * p1.x + c1 * p2.x, a0.y + c2 * p1.y + c1 * p2.y);
-        const V n1 = rot<INV>(mkv<V>(s1 * q1.x + s2 * q2.x, s1 * q1.y + s2 * q2.y));
-        const V n2 = rot<INV>(mkv<V>(s2 * q1.x - s1 * q2.x, s2 * q1.y - s1 * q2.y));
-        v[0] = cadd(a0, cadd(p1, p2));
-        v[1] = cadd(m1, n1);
-        v[2] = cadd(m2, n2);
-        v[3] = csub(m2, n2);
-        v[4] = csub(m1, n1);
-    }
-}
-
-// R-point DFT of v[m], m = R2 m1 + m2, result v[q], q = q1 + R1 q2:
-//   W_R^(m q) = W_R1^(m1 q1) . W_R^(m2 q1) . W_R2^(m2 q2);   W_R^t = tw[t * wstep], wstep = N / R
-template <int R1, int R2, bool INV, typename V>
-__device__ __forceinline__ void dft_composite(V (&v)[R1 * R2], const V *tw, int wstep) {
-    if constexpr (R2 == 1) {
-        butterfly<R1, INV>(v);
-    } else {
-    V a[R1 * R2];                                  // a[q1 R2 + m2]
-#pragma unroll
-    for (int m2 = 0; m2 < R2; ++m2) {
-        V t[R1];
-#pragma unroll
-        for (int m1 = 0; m1 < R1; ++m1) t[m1] = v[R2 * m1 + m2];
-        butterfly<R1, INV>(t);
-#pragma unroll
-        for (int q1 = 0; q1 < R1; ++q1) a[q1 * R2 + m2] = t[q1];
-    }
-#pragma unroll
-    for (int q1 = 1; q1 < R1; ++q1)
-#pragma unroll
-        for (int m2 = 1; m2 < R2; ++m2) a[q1 * R2 + m2] = cmul(a[q1 * R2 + m2], twid<INV>(tw, (m2 * q1) * wstep));
-#pragma unroll
-    for (int q1 = 0; q1 < R1; ++q1) {
-        V t[R2];
-#pragma unroll
-        for (int m2 = 0; m2 < R2; ++m2) t[m2] = a[q1 * R2 + m2];
-        butterfly<R2, INV>(t);
-#pragma unroll
-        for (int q2 = 0; q2 < R2; ++q2) v[q1 + R1 * q2] = t[q2];
-    }
-    }
-}
-
-// one Stockham pass, one butterfly per thread.  src(i) -> V reads element i of the pass input,
-// dst(i, V) writes element i of its output; `fence` = both are the same LDS buffer.
-template <int R1, int R2, bool INV, typename V, typename Src, typename Dst>
-__device__ __forceinline__ void composite_pass(const Src &src, const Dst &dst, bool fence, const V *tw, int N, int Ns,
-                                               unsigned magic) {
-    constexpr int R = R1 * R2;
-    const int nb = N / R;
-    const int b = threadIdx.x;
-    const bool act = b < nb;
-    V v[R];
-    int j0 = 0;
-    if (act) {
-        const int blk = Ns == 1 ? b : (int)__umulhi((unsigned)b, magic);
-        const int k = b - blk * Ns;
-        j0 = blk * Ns * R + k;
-#pragma unroll
-        for (int m = 0; m < R; ++m) v[m] = src(b + m * nb);
-        if (Ns > 1) {
-            // pass twiddles w^(m t1): ONE gathered table entry per butterfly (the lanes' indices are
-            // strided, so a gather costs a cache line per lane), the powers by squaring / one product
-            const int t1 = k * (nb / Ns);          // k * N / (Ns R)
-            V wp[R];
-            wp[1] = twid<INV>(tw, t1);
-#pragma unroll
-            for (int m = 2; m < R; ++m) wp[m] = (m % 2 == 0) ? cmul(wp[m / 2], wp[m / 2]) : cmul(wp[m - 1], wp[1]);
-#pragma unroll
-            for (int m = 1; m < R; ++m) v[m] = cmul(v[m], wp[m]);
-        }
-        dft_composite<R1, R2, INV>(v, tw, nb);
-    }
-    if (fence) __syncthreads();
-    if (act) {
-#pragma unroll
-        for (int q = 0; q < R; ++q) dst(j0 + q * Ns, v[q]);
-    }
-    __syncthreads();
-}
-
-template <int MAXR, bool INV, typename V, typename Src, typename Dst>
-__device__ __forceinline__ void pass_dispatch(int r1, int r2, const Src &src, const Dst &dst, bool fence, const V *tw,
-                                              int N, int Ns, unsigned magic) {
-#define GCM_PASS(A, B)                                                                      \
-    case (A) * 8 + (B):                                                                     \
-        if constexpr ((A) * (B) <= MAXR) composite_pass<A, B, INV>(src, dst, fence, tw, N, Ns, magic); \
-        break;
-    switch (r1 * 8 + r2) {
-        GCM_PASS(2, 1) GCM_PASS(3, 1) GCM_PASS(4, 1) GCM_PASS(5, 1)
-        GCM_PASS(3, 2) GCM_PASS(4, 2) GCM_PASS(3, 3) GCM_PASS(5, 2) GCM_PASS(4, 3)
-        GCM_PASS(5, 3) GCM_PASS(4, 4) GCM_PASS(5, 4) GCM_PASS(5, 5)
-        default: break;
-    }
-#undef GCM_PASS
-}
-
-// Filter the two real rows that `load(i)` delivers as re/im: forward FFT, multiply by S[n]/N
-// (n folded, low_pass.py:61-72; numpy's irfft scales by 1/N), inverse FFT, `store(i, V)`.
-template <int MAXR, typename T, typename Load, typename Store>
-__device__ __forceinline__ void filter_rows_composite(typename Vec2<T>::type *x, const Load &load, const Store &store,
-                                                      const typename Vec2<T>::type *tw, const SuperPlan &P, int N,
-                                                      const T *S) {
-    using V = typename Vec2<T>::type;
-    const T inv_n = T(1.0) / (T)N;
-    const auto lds_src = [x](int i) { return x[i]; };
-    const auto lds_dst = [x](int i, V v) { x[i] = v; };
-    const auto lds_src_filtered = [x, S, N, inv_n](int i) {
-        const T s = S[i <= N / 2 ? i : N - i] * inv_n;
-        const V v = x[i];
-        return mkv<V>(v.x * s, v.y * s);
-    };
-    // the first and the last pass of either direction are written out rather than selected inside
-    // one loop: their global addresses would otherwise be hoisted out of it and pinned in registers
-    const int np = P.npass;
-    int Ns = P.r1[0] * P.r2[0];
-    pass_dispatch<MAXR, false>(P.r1[0], P.r2[0], load, lds_dst, false, tw, N, 1, P.magic[0]);
-    for (int pass = 1; pass < np; ++pass) {
-        pass_dispatch<MAXR, false>(P.r1[pass], P.r2[pass], lds_src, lds_dst, true, tw, N, Ns, P.magic[pass]);
-        Ns *= P.r1[pass] * P.r2[pass];
-    }
-    if (np == 1) {
-        pass_dispatch<MAXR, true>(P.r1[0], P.r2[0], lds_src_filtered, store, false, tw, N, 1, P.magic[0]);
-        return;
-    }
-    pass_dispatch<MAXR, true>(P.r1[0], P.r2[0], lds_src_filtered, lds_dst, true, tw, N, 1, P.magic[0]);
-    Ns = P.r1[0] * P.r2[0];
-    for (int pass = 1; pass < np - 1; ++pass) {
-        pass_dispatch<MAXR, true>(P.r1[pass], P.r2[pass], lds_src, lds_dst, true, tw, N, Ns, P.magic[pass]);
-        Ns *= P.r1[pass] * P.r2[pass];
-    }
-    pass_dispatch<MAXR, true>(P.r1[np - 1], P.r2[np - 1], lds_src, store, false, tw, N, Ns, P.magic[np - 1]);
-}
-
-// filter two real rows held as re/im of x[0..N): FFT, multiply by S[n] (n folded), inverse FFT.
-// Returns the buffer holding the result (already scaled by 1/N).
-template <typename T>
-__device__ typename Vec2<T>::type *filter_rows(typename Vec2<T>::type *x, typename Vec2<T>::type *y, const PeArgsT<T> &a, int jglob) {
-    using T2 = typename Vec2<T>::type;
-    const int N = a.W;
-    T2 *z = fft_lds<false>(x, y, a.tw, a.plan);
-    const T *S = a.smul + (long)jglob * (N / 2 + 1);
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        const T s = S[n <= N / 2 ? n : N - n];
-        z[n].x *= s;
-        z[n].y *= s;
-    }
-    __syncthreads();
-    T2 *o = (z == x) ? y : x;
-    T2 *res = fft_lds<true>(z, o, a.tw, a.plan);
-    const T inv_n = T(1.0) / (T)N;
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        res[n].x *= inv_n;
-        res[n].y *= inv_n;
-    }
-    __syncthreads();
-    return res;
-}
-
 // ---------------------------------------------------------------- K1: spu = filter(su * iph(sp))
 constexpr int kFftThreads = 256;    // generic path; the composite path sizes the workgroup from its plan
 template <typename T, int MAXR>
@@ -433,7 +108,7 @@ __global__ __launch_bounds__(512) void pe_spu_filter_kernel(PeArgsT<T> a) {
         } else {
             for (int i = threadIdx.x; i < W; i += blockDim.x) x[i] = load(i);
             __syncthreads();
-            const V *res = filter_rows(x, x + W, a, wrapi(a.row0 + j, a.Hg));
+            const V *res = filter_rows<T>(x, x + W, a.tw, a.plan, a.smul + (long)wrapi(a.row0 + j, a.Hg) * (W / 2 + 1));
             for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, res[i]);
         }
     } else {
@@ -623,7 +298,7 @@ __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
         } else {
             for (int i = threadIdx.x; i < W; i += blockDim.x) x[i] = load(i);
             __syncthreads();
-            const V *res = filter_rows(x, x + W, a, jg);
+            const V *res = filter_rows<T>(x, x + W, a.tw, a.plan, a.smul + (long)jg * (W / 2 + 1));
             for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, res[i]);
         }
     } else {
@@ -992,61 +667,6 @@ struct Pe25d {
 template <typename T> static PeBufs<T> &bufs(Pe25d *m);
 template <> PeBufs<double> &bufs<double>(Pe25d *m) { return m->d; }
 template <> PeBufs<float> &bufs<float>(Pe25d *m) { return m->f; }
-
-static bool make_plan(int n, FftPlan *P) {
-    P->n = n;
-    P->nrad = 0;
-    int m = n;
-    auto push = [&](int r) { if (P->nrad < kMaxRadices) P->rad[P->nrad++] = r; };
-    while (m % 4 == 0) { push(4); m /= 4; }
-    while (m % 2 == 0) { push(2); m /= 2; }
-    for (int r = 3; r <= m && m > 1; r += 2)
-        while (m % r == 0) { push(r); m /= r; }
-    long Ns = 1;
-    for (int i = 0; i < P->nrad; ++i) {
-        P->magic[i] = (unsigned)(((1ULL << 32) + (unsigned long long)Ns - 1) / (unsigned long long)Ns);
-        Ns *= P->rad[i];
-    }
-    return m == 1 && P->nrad <= kMaxRadices;
-}
-
-// composite-radix plan: n = product of base radices {5,4,3,2} (pairs of 2s become 4s), sorted
-// descending and paired largest-with-smallest into passes of radix r1 * r2 (1440 -> 5.2, 4.3, 4.3;
-// 2880 -> 5.3, 4.3, 4.4).  ok = 0 when n has a prime factor > 5 or a pass is wider than 512
-// butterflies (the workgroup has one thread per butterfly).
-static void make_super_plan(int n, SuperPlan *P) {
-    *P = SuperPlan{};
-    std::vector<int> base;
-    int m = n;
-    while (m % 5 == 0) { base.push_back(5); m /= 5; }
-    int twos = 0;
-    while (m % 2 == 0) { ++twos; m /= 2; }
-    for (int i = 0; i < twos / 2; ++i) base.push_back(4);
-    while (m % 3 == 0) { base.push_back(3); m /= 3; }
-    if (twos % 2) base.push_back(2);
-    if (m != 1 || base.empty()) return;
-    std::sort(base.begin(), base.end(), [](int x, int y) { return x > y; });
-    int lo = 0, hi = (int)base.size() - 1;
-    long Ns = 1;
-    int widest = 1;
-    while (lo <= hi) {
-        if (P->npass == kMaxSuper) return;
-        const int r1 = base[lo], r2 = lo < hi ? base[hi] : 1;
-        // 2 x 2 never occurs (pairs of 2s are 4s); r1 >= r2 by the sort
-        P->r1[P->npass] = r1;
-        P->r2[P->npass] = r2;
-        P->magic[P->npass] = (unsigned)(((1ULL << 32) + (unsigned long long)Ns - 1) / (unsigned long long)Ns);
-        Ns *= (long)r1 * r2;
-        if (r1 * r2 > P->maxr) P->maxr = r1 * r2;
-        if (n / (r1 * r2) > widest) widest = n / (r1 * r2);
-        ++P->npass;
-        ++lo;
-        --hi;
-    }
-    if (widest > 512) return;
-    P->threads = (widest + 63) / 64 * 64;
-    P->ok = 1;
-}
 
 template <typename T>
 static bool dev_upload(Pe25d *m, T **dst, const T *src, size_t count) {
