@@ -131,7 +131,7 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
     """-> dict(value, ms_per_step, [roofline]) measured on `world` ranks (default: all)"""
     import gcmiipy_amd as g
     from gcmiipy_amd import _lib, geometry
-    from gcmiipy_amd.bands import BandRunner, HipBandEngine, split_rows
+    from gcmiipy_amd.bands import BandRunner, HipBandEngine, LoopbackExchange, split_rows
     torch, dist = cx.torch, cx.dist
     world = cx.world if world is None else world
     solo = world == 1 and cx.world > 1                # 1-GPU reference inside an N-rank job
@@ -178,6 +178,7 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
     fence()
     t0 = time.perf_counter()
     run(steps, timed=True)
+    t_queued = time.perf_counter() - t0               # the host has queued all K steps
     fence()
     el = time.perf_counter() - t0
     if dist is not None and not solo:
@@ -195,6 +196,24 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
                "hbm_roofline_frac_whole_job": value * bpc / (world * HBM_PEAK_GBS * 1e9),
                "decomposition": "%d latitude band(s)%s" % (
                    world, ", ghost rows exchanged every %d steps" % k if world > 1 and k > 1 else "")}
+        if world > 1:
+            # diagnostics for the multi-GPU line: how long the host needs to queue a step, and what
+            # the same band costs with the exchange replaced by a device-local copy (same launches
+            # and stream dependencies, no xGMI traffic) -- the difference to ms_per_step is what the
+            # exchange adds.  Run AFTER the timed region; its ghost rows are not a model state.
+            lb = BandRunner(eng, rank, world, LoopbackExchange())
+            lb.primed, lb.count = True, 0
+            nlb = max(k, 8) * 4
+            lb.run(nlb, dt)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            lb.run(nlb, dt)
+            e1.record()
+            torch.cuda.synchronize()
+            res["diagnostics"] = {"host_queue_ms_per_step": t_queued / steps * 1e3,
+                                  "band_ms_per_step_local_exchange": e0.elapsed_time(e1) / nlb,
+                                  "rank": rank}
         if world == 1 and want_kernel:
             # dominant kernel.  fused 2-D: one launch per step, so its average duration over the
             # timed region is (HIP-event time of the region on the launch stream) / launches; the
@@ -303,6 +322,8 @@ def main():
         }
         if "roofline" in main_res:
             out["roofline"] = main_res["roofline"]
+        if "diagnostics" in main_res:
+            out["diagnostics"] = main_res["diagnostics"]
         if cx.world == 1:
             out["cpu_baseline"] = None if a.no_cpu else cpu_baseline(a.workload)
         if also:

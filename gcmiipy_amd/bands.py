@@ -150,6 +150,31 @@ class BandRunner:
             self.step(dt)
 
 
+class LoopbackExchange:
+    """Diagnostic stand-in for torch.distributed inside BandRunner: every send lands in the
+    matching receive buffer of the SAME rank (a device-local copy on the comm stream).  The band
+    then steps with all of its launches and stream dependencies but no xGMI traffic, which
+    separates what the kernels cost from what the exchange costs (bench.py, tools_band_time.py).
+    The numbers it produces are not a model state (the ghost rows are the band's own edge rows)."""
+
+    class _Req:
+        def wait(self):
+            pass
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    isend, irecv = "isend", "irecv"
+
+    def batch_isend_irecv(self, ops):
+        sends = [o.tensor for o in ops if o.op == "isend"]
+        recvs = [o.tensor for o in ops if o.op == "irecv"]
+        for s, r in zip(sends, recvs):
+            r.copy_(s, non_blocking=True)
+        return [self._Req()]
+
+
 class HipBandEngine:
     """A `Core` band + torch CUDA buffers/streams for the exchange."""
 

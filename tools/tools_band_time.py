@@ -20,28 +20,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-class LoopbackDist:
-    """stands in for torch.distributed inside BandRunner: every send lands in the matching
-    receive buffer of the same rank (north edge -> south ghost and vice versa)."""
-
-    class _Req:
-        def wait(self):
-            pass
-
-    class P2POp:
-        def __init__(self, op, tensor, peer):
-            self.op, self.tensor, self.peer = op, tensor, peer
-
-    isend, irecv = "isend", "irecv"
-
-    def batch_isend_irecv(self, ops):
-        sends = [o.tensor for o in ops if o.op == "isend"]
-        recvs = [o.tensor for o in ops if o.op == "irecv"]
-        for s, r in zip(sends, recvs):     # BandRunner's order: sends N,S; receives S,N
-            r.copy_(s, non_blocking=True)
-        return [self._Req()]
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c4")
@@ -53,7 +31,7 @@ def main():
     import bench
     import gcmiipy_amd as g
     from gcmiipy_amd import _lib, geometry
-    from gcmiipy_amd.bands import BandRunner, HipBandEngine, split_rows
+    from gcmiipy_amd.bands import BandRunner, HipBandEngine, LoopbackExchange as LoopbackDist, split_rows
     torch.cuda.set_device(0)
     _shift = [torch.cuda.Stream() for _ in range(int(os.environ.get("GCM_TEST_STREAM_SHIFT", "0")))]
     for st in _shift:
