@@ -249,6 +249,7 @@ struct FusedCtx {
     // r-2, r-1; SN is a dead slot that receives predicted row r.  On exit BM's slot holds
     // base row r+2 (from the prefetched `nxt`) and `nxt` is row r+3: the caller rotates the
     // slot names instead of moving registers.
+    template <bool FETCH = true>
     __device__ __forceinline__ void iter(int r, Row &BM, Row &B0, Row &BP, Row &SN, Row &SM,
                                          Row &S0, Raw &nxt, double &qmm, double &qm, double &q0,
                                          double &qp) {
@@ -302,11 +303,27 @@ struct FusedCtx {
             q0 = qp;
             qp = nxt.q;
         }
-        if (r + 3 <= jb + 1) nxt = load(r + 3);
+        if (FETCH && r + 3 <= jb + 1) nxt = load(r + 3);   // !FETCH: the caller has the rows already
     }
 };
 
-template <bool TEMP, int TRACER, bool WRAPJ>
+// Short bands (small grids: a band is 2-4 rows): the rows are all loaded before the first one is
+// used, and the iterations are unrolled with the window slots rotated by name.  A wave then waits
+// for memory once instead of once per row, which is most of its life on a 720x360 grid.
+template <int N, int PRE, class Ctx>
+__device__ __forceinline__ void preloaded_iters(Ctx &c, const Raw (&pre)[PRE + 4], Row &A, Row &B, Row &C, Row &X,
+                                                Row &Y, Row &Z, Raw &nxt, double &qmm, double &qm, double &q0,
+                                                double &qp) {
+    if constexpr (N < PRE + 2) {
+        const int r = c.ja - 1 + N;
+        if (r > c.jb) return;
+        c.template iter<false>(r, A, B, C, X, Y, Z, nxt, qmm, qm, q0, qp);
+        if constexpr (N < PRE) nxt = pre[N + 4];          // row r + 3
+        preloaded_iters<N + 1, PRE>(c, pre, B, C, A, Y, Z, X, nxt, qmm, qm, q0, qp);
+    }
+}
+
+template <bool TEMP, int TRACER, bool WRAPJ, int PRE = 0>
 __global__ __launch_bounds__(64) void sw2d_fused_kernel(Sw2dArgs a) {
     const int W = a.W;
     const int lane = threadIdx.x;
@@ -336,6 +353,19 @@ __global__ __launch_bounds__(64) void sw2d_fused_kernel(Sw2dArgs a) {
     const int ja = c.ja, jb = c.jb;
 
     Row A, B, C, X, Y, Z;
+    if constexpr (PRE > 0) {               // rows_per_band <= PRE
+        Raw pre[PRE + 4];
+#pragma unroll
+        for (int n = 0; n < PRE + 4; ++n) pre[n] = c.load(min(ja - 2 + n, jb + 1));
+        make_row<TEMP>(A, pre[0].u, pre[0].v, pre[0].p, pre[0].t, tab);
+        make_row<TEMP>(B, pre[1].u, pre[1].v, pre[1].p, pre[1].t, tab);
+        make_row<TEMP>(C, pre[2].u, pre[2].v, pre[2].p, pre[2].t, tab);
+        double qmm = 0.0, qm = pre[0].q, q0 = pre[1].q, qp = pre[2].q;
+        Raw nxt = pre[3];
+        X = Y = Z = A;
+        preloaded_iters<0, PRE>(c, pre, A, B, C, X, Y, Z, nxt, qmm, qm, q0, qp);
+        return;
+    }
     Raw x = c.load(ja - 2);
     make_row<TEMP>(A, x.u, x.v, x.p, x.t, tab);
     double qmm = 0.0, qm = x.q;
@@ -358,14 +388,21 @@ __global__ __launch_bounds__(64) void sw2d_fused_kernel(Sw2dArgs a) {
     }
 }
 
+constexpr int kPreloadRows = 4;     // bands of up to this many rows use the preloading variant (plain SW2D)
+
 template <bool TEMP, int TRACER>
 static const void *fused_fn(bool wrap) {
     return wrap ? (const void *)sw2d_fused_kernel<TEMP, TRACER, true>
                 : (const void *)sw2d_fused_kernel<TEMP, TRACER, false>;
 }
 
-static const void *fused_kernel_ptr(bool temp, int tracer, bool wrap) {
-    if (!temp) return fused_fn<false, 0>(wrap);
+static const void *fused_kernel_ptr(bool temp, int tracer, bool wrap, int rows_per_band = 1 << 30) {
+    if (!temp) {
+        if (rows_per_band <= kPreloadRows)
+            return wrap ? (const void *)sw2d_fused_kernel<false, 0, true, kPreloadRows>
+                        : (const void *)sw2d_fused_kernel<false, 0, false, kPreloadRows>;
+        return fused_fn<false, 0>(wrap);
+    }
     if (tracer == 0) return fused_fn<true, 0>(wrap);
     if (tracer == 1) return fused_fn<true, 1>(wrap);
     return fused_fn<true, 2>(wrap);
@@ -408,7 +445,7 @@ void launch_sw2d_fused(const Sw2dArgs &a, bool temp, int tracer, hipStream_t s) 
     dim3 g((unsigned)(((long)strips * bands + 7) / 8 * 8));  // 1-D, padded to 8 XCD groups
     Sw2dArgs arg = a;
     void *params[] = {&arg};
-    (void)hipLaunchKernel(fused_kernel_ptr(temp, tracer, a.wrap_j != 0), g, dim3(64), params, 0, s);
+    (void)hipLaunchKernel(fused_kernel_ptr(temp, tracer, a.wrap_j != 0, a.rows_per_band), g, dim3(64), params, 0, s);
 }
 
 __global__ void copy_rows_kernel(double *dst, const double *src, long n) {
