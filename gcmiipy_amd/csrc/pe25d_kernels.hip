@@ -347,6 +347,7 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgsT<T> a) {
     const T inv_pnu = rcp((pn_c + pn_e) * T(0.5)), inv_pnv = rcp((pn_c + pn_s) * T(0.5)), inv_pn = rcp(pn_c);
     const bool pole_edge = jg == a.Hg - 1;
     const bool coriolis = a.cor_u != nullptr;
+    const bool same = a.u == a.su;
     const T cp_u = coriolis ? a.cor_u[jg] : T(0.0), cp_v = coriolis ? a.cor_v[jg] : T(0.0);
     if (seg == 0) a.op[(long)j * W + i] = pn_c;
 
@@ -442,8 +443,9 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgsT<T> a) {
         const T dts = -((((st_c + st_m) * T(0.5)) * sd_c - ((st_p + st_c) * T(0.5)) * sd_cp) * inv_ds);
         const T dqs = -((((sq_c + sq_m) * T(0.5)) * sd_c - ((sq_p + sq_c) * T(0.5)) * sd_cp) * inv_ds);
         // ---- momentum update, dynamics.py:186-212
-        const T pu = a.u[rc + kc + i] * iph_pb;
-        const T pv = a.v[rc + kc + i] * jph_pb;
+        // predictor: the stage state IS the base state, its values are in the window already
+        const T pu = (same ? su_c : a.u[rc + kc + i]) * iph_pb;
+        const T pv = (same ? sv_c : a.v[rc + kc + i]) * jph_pb;
         const T pgfu = a.pgfu[rc + kc + i];
         const T pu_n = pu - (dut + dus + pgfu) * dt;
         const T pv_n = pv - (dvt + dvs + phiv + pgv) * dt;
@@ -459,8 +461,8 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgsT<T> a) {
                            (spv_c * ((st_c + st_s) * T(0.5)) - spv_n * ((st_n + st_c) * T(0.5))) * inv_dy;
         const T adq = (spu_c * ((sq_c + sq_e) * T(0.5)) - spu_w * ((sq_w + sq_c) * T(0.5))) * inv_dxj +
                            (spv_c * ((sq_c + sq_s) * T(0.5)) - spv_n * ((sq_n + sq_c) * T(0.5))) * inv_dy;
-        const T t_n = (a.t[rc + kc + i] * pb_c - (adt + dts) * dt) * inv_pn;
-        const T q_n = (a.q[rc + kc + i] * pb_c - (adq + dqs) * dt) * inv_pn;
+        const T t_n = ((same ? st_c : a.t[rc + kc + i]) * pb_c - (adt + dts) * dt) * inv_pn;
+        const T q_n = ((same ? sq_c : a.q[rc + kc + i]) * pb_c - (adq + dqs) * dt) * inv_pn;
         const long o = (long)j * L * W + kc + i;                 // interior rows: no wrap needed
         a.ou[o] = u_n;
         a.ov[o] = v_n;
