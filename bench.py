@@ -239,6 +239,24 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
                 traffic = tj[name][("gcm::" + kname.split(" ")[0])]["hbm_bytes_per_launch"]   # fp64 runs only
             except Exception:
                 pass
+            # context: what a plain device-to-device copy of the same bytes (state in, state out)
+            # reaches on this box, timed the same way
+            nb = int(cells * bpc / 2)
+            src = torch.empty(nb // 8, dtype=torch.float64, device="cuda").normal_()
+            dst = torch.empty_like(src)
+            for _ in range(3):
+                dst.copy_(src)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 2.0 * nb / (e0.elapsed_time(e1) / 20 * 1e-3) / 1e9
+            del src, dst
+            res["device_copy_same_bytes"] = {"GB/s": copy_gbs, "kernel_traffic_over_copy_rate":
+                                             (traffic or cells * bpc / launches) / (kms * 1e-3) / 1e9 / copy_gbs}
             res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                                "kernel_ms": kms, "kernel_ms_isolated": kiso,
@@ -324,6 +342,8 @@ def main():
             out["roofline"] = main_res["roofline"]
         if "diagnostics" in main_res:
             out["diagnostics"] = main_res["diagnostics"]
+        if "device_copy_same_bytes" in main_res:
+            out["device_copy_same_bytes"] = main_res["device_copy_same_bytes"]
         if cx.world == 1:
             out["cpu_baseline"] = None if a.no_cpu else cpu_baseline(a.workload)
         if also:
