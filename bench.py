@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SETTLE_S = float(os.environ.get("GCM_BENCH_SETTLE_S", "0.15"))   # untimed pre-conditioning before warm-up (see run_workload)
 
 WORKLOADS = {
     # name: (description, H, W, L, model, tracer, bytes per cell-update = 2 * fields * 8, dt)
@@ -155,14 +156,34 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
         runner = BandRunner(eng, rank, world, dist)
         region = {}
 
-        def run(n, timed=False):
+        def run_chunk(n, timed):
             if world == 1:
                 if timed:   # same launches, bracketed by HIP events on the launch stream
-                    region["ms"], _ = core.time_steps(n, dt, per_kernel=False)
+                    region["ms"] = region.get("ms", 0.0) + core.time_steps(n, dt, per_kernel=False)[0]
                 else:
                     core.step(n, dt)
             else:
                 runner.run(n, dt)
+
+        # The SURVEY's noise initial state of the 2-D workloads is not a balanced flow: it goes
+        # non-finite after ~1100 (c3) / ~1300 (c2) steps, in the reference as here.  A run longer
+        # than `life` steps goes back to the initial state (a device-side copy, gcm_restore, inside
+        # the timed region: one 0.1 ms copy per `life` steps), at an exchange boundary on bands.
+        life = {"c3": 400, "c2": 800}.get(name)
+        if life is not None:
+            life = life // k * k
+            core.snapshot()
+        since = [0]
+
+        def run(n, timed=False):
+            while n > 0:
+                m = n if life is None else min(n, life - since[0])
+                run_chunk(m, timed)
+                since[0] += m
+                n -= m
+                if life is not None and since[0] == life:
+                    core.restore()
+                    since[0] = 0
     else:
         def run(n, timed=False):
             pass
@@ -174,6 +195,27 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
 
     if dist is not None:
         dist.barrier()
+    # Untimed pre-conditioning: the chip needs some tens of milliseconds of sustained load before it
+    # runs at its sustained clock (the same 400 steps of c3 take 0.153 ms each from idle and 0.146
+    # after 60 ms of load).  SETTLE_S seconds of the same steps, then back to the initial state
+    # (2-D workloads), then the W warm-up steps and the K timed steps of the contract.
+    if active:
+        t0 = time.perf_counter()
+        run(2 * k)
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - t0) / (2 * k)
+    else:
+        per = 0.0
+    if dist is not None and not solo:
+        tt = torch.tensor([per], dtype=torch.float64, device="cuda" if cx.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        per = float(tt.item())
+    if active:
+        n_settle = min(20000, int(SETTLE_S / max(per, 1e-6))) // k * k
+        run(n_settle)
+        if life is not None and since[0]:
+            core.restore()
+            since[0] = 0
     run(warmup)
     fence()
     t0 = time.perf_counter()

@@ -59,6 +59,8 @@ SYMBOLS = {
     "gcm_get_ground": (C.c_int, [_H, C.c_void_p]),
     "gcm_grey_radiation": (C.c_int, [_H] + [C.c_double] * 4 + [_dp, _dp, C.c_void_p, C.c_void_p]),
     "gcm_solar_step": (C.c_int, [_H] + [C.c_double] * 5 + [_dp, _dp]),
+    "gcm_snapshot": (C.c_int, [_H]),
+    "gcm_restore": (C.c_int, [_H]),
     "gcm_halo_bytes": (C.c_size_t, [_H]),
     "gcm_halo_pack": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
     "gcm_halo_unpack": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),

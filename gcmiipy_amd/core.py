@@ -141,6 +141,14 @@ class Core:
     def half_step(self, stage, dt):
         _check(lib.gcm_half_step(self._h, int(stage), float(dt)), self._h)
 
+    def snapshot(self):
+        """device-side copy of the current state (2-D models)"""
+        _check(lib.gcm_snapshot(self._h), self._h)
+
+    def restore(self):
+        """current state <- snapshot, asynchronously on the handle's stream"""
+        _check(lib.gcm_restore(self._h), self._h)
+
     def sync(self):
         _check(lib.gcm_sync(self._h), self._h)
 

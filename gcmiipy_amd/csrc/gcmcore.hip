@@ -36,6 +36,8 @@ struct gcm_handle {
     int G = kGhost;          // ghost rows per side = 2 * steps between exchanges (2-D bands)
     int since_exchange = 0;  // steps taken on the current ghost rows
     bool star_valid = false;
+    double *snap[GCM_NFIELDS] = {};   // gcm_snapshot: device copy of the state, ghost rows included
+    int snap_since_exchange = 0;
     int variant = GCM_VARIANT_FUSED;
     int rows_per_band = 32;
 
@@ -555,6 +557,44 @@ int gcm_halo_pack2(gcm_handle *h, void *north_buf, void *south_buf, void *stream
 int gcm_halo_unpack2(gcm_handle *h, const void *north_buf, const void *south_buf, void *stream) {
     if (!h || !north_buf || !south_buf) return GCM_ERR_ARG;
     return halo_run(h, false, (void *)north_buf, (void *)south_buf, stream);
+}
+
+// Device-side snapshot of the current state (2-D models): lets a long run restart from a known
+// state without a host round trip (bench.py: the SURVEY's noise initial state lives for a few
+// hundred steps only).  gcm_restore is asynchronous on the handle's stream.
+int gcm_snapshot(gcm_handle *h) {
+    if (!h) return GCM_ERR_ARG;
+    if (h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_snapshot: 2-D models only");
+    const size_t n = (size_t)(h->H + 2 * h->G) * h->W;
+    for (int f = 0; f < GCM_NFIELDS; ++f) {
+        if (!h->has[f]) continue;
+        if (!h->snap[f]) {
+            void *d = nullptr;
+            HIPCHK(h, hipMalloc(&d, n * sizeof(double)));
+            h->allocs.push_back(d);
+            h->snap[f] = (double *)d;
+        }
+        HIPCHK(h, hipMemcpyAsync(h->snap[f], h->cur[f] - (size_t)h->G * h->W, n * sizeof(double),
+                                 hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->snap_since_exchange = h->since_exchange;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return GCM_OK;
+}
+
+int gcm_restore(gcm_handle *h) {
+    if (!h) return GCM_ERR_ARG;
+    if (h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_restore: 2-D models only");
+    const size_t n = (size_t)(h->H + 2 * h->G) * h->W;
+    for (int f = 0; f < GCM_NFIELDS; ++f) {
+        if (!h->has[f]) continue;
+        if (!h->snap[f]) return fail(h, GCM_ERR_STATE, "gcm_restore: no snapshot taken");
+        HIPCHK(h, hipMemcpyAsync(h->cur[f] - (size_t)h->G * h->W, h->snap[f], n * sizeof(double),
+                                 hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->since_exchange = h->snap_since_exchange;
+    h->star_valid = false;
+    return GCM_OK;
 }
 
 int gcm_sync(gcm_handle *h) {

@@ -177,6 +177,12 @@ int gcm_grey_radiation(gcm_handle *h, double utc, double t_lw, double t_sw, doub
 int gcm_solar_step(gcm_handle *h, double dt, double utc, double t_lw, double t_sw, double albedo,
                    const double *lat, const double *lon);
 
+/* Device-side snapshot / restore of the current state, ghost rows included (2-D models): a long
+ * run can restart from a known state without a host round trip.  gcm_restore is asynchronous on
+ * the handle's stream.                                                                          */
+int gcm_snapshot(gcm_handle *h);
+int gcm_restore(gcm_handle *h);
+
 /* Latitude-band ghost rows (nranks > 1).  The library packs the rows a neighbour
  * needs into / unpacks them from caller-owned DEVICE buffers (e.g. torch tensors
  * handed to torch.distributed / RCCL send-recv); it never calls a collective

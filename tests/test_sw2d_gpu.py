@@ -174,3 +174,32 @@ def test_fused_equals_staged_full_size(g):
         for a, b in zip(*res):
             if a is not None:
                 assert rel_err(a, b) < 1e-13
+
+
+def test_snapshot_restore_is_bit_exact(g):
+    """gcm_snapshot / gcm_restore (device-side copy of the state): stepping on from a restored state
+    reproduces the steps taken from the original one bit for bit; restore without a snapshot fails"""
+    rng = np.random.default_rng(5)
+    H, W = 40, 130
+    u, v = rng.standard_normal((H, W)), rng.standard_normal((H, W))
+    p, t, q = 101325 + rng.standard_normal((H, W)), 273.16 + rng.standard_normal((H, W)), rng.random((H, W))
+    c = g.Core(g._lib.SW2D_TEMP, W, H, dx=300e3, tracer=g._lib.TRACER_VANLEER)
+    c.set_state(p=p, u=u, v=v, t=t, q=q)
+    with pytest.raises(g.core.GcmError):
+        c.restore()
+    c.step(3, 300.0)
+    c.snapshot()
+    c.step(7, 300.0)
+    first = c.get_state()
+    c.restore()
+    back = c.get_state()
+    c.step(7, 300.0)
+    again = c.get_state()
+    c.set_state(p=p, u=u, v=v, t=t, q=q)
+    c.step(3, 300.0)
+    at3 = c.get_state()
+    c.close()
+    for a, b in zip(back, at3):
+        assert np.array_equal(a, b)
+    for a, b in zip(first, again):
+        assert np.array_equal(a, b)
