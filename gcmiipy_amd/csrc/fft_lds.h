@@ -23,6 +23,7 @@ constexpr int kMaxSuper = 8;
 struct SuperPlan {
     int ok;                        // 0: use the generic ping-pong path
     int npass, threads, maxr;      // workgroup size = widest pass rounded up to whole waves
+    unsigned mask;                 // pass_bit() of every pass
     int r1[kMaxSuper], r2[kMaxSuper];
     unsigned magic[kMaxSuper];     // ceil(2^32 / Ns) of the pass
 };
@@ -259,12 +260,23 @@ __device__ __forceinline__ void composite_pass(const Src &src, const Dst &dst, b
     __syncthreads();
 }
 
-template <int MAXR, bool INV, typename V, typename Src, typename Dst>
+// MAXR: widest radix compiled in.  MASK != 0: only the passes whose bit is set (bit = position in
+// the list below) -- a kernel instantiated for one plan's own radices; the register allocation
+// of a kernel is that of its hungriest compiled-in pass, used or not.
+constexpr unsigned pass_bit(int a, int b) {
+    return a == 2 ? 1u << 0 : (a == 3 && b == 1) ? 1u << 1 : (a == 4 && b == 1) ? 1u << 2 : (a == 5 && b == 1) ? 1u << 3
+         : (a == 3 && b == 2) ? 1u << 4 : (a == 4 && b == 2) ? 1u << 5 : (a == 3 && b == 3) ? 1u << 6
+         : (a == 5 && b == 2) ? 1u << 7 : (a == 4 && b == 3) ? 1u << 8 : (a == 5 && b == 3) ? 1u << 9
+         : (a == 4 && b == 4) ? 1u << 10 : (a == 5 && b == 4) ? 1u << 11 : 1u << 12;
+}
+
+template <int MAXR, unsigned MASK, bool INV, typename V, typename Src, typename Dst>
 __device__ __forceinline__ void pass_dispatch(int r1, int r2, const Src &src, const Dst &dst, bool fence, const V *tw,
                                               int N, int Ns, unsigned magic) {
 #define GCM_PASS(A, B)                                                                      \
     case (A) * 8 + (B):                                                                     \
-        if constexpr ((A) * (B) <= MAXR) composite_pass<A, B, INV>(src, dst, fence, tw, N, Ns, magic); \
+        if constexpr ((A) * (B) <= MAXR && (MASK == 0 || (MASK & pass_bit(A, B)) != 0))     \
+            composite_pass<A, B, INV>(src, dst, fence, tw, N, Ns, magic);                   \
         break;
     switch (r1 * 8 + r2) {
         GCM_PASS(2, 1) GCM_PASS(3, 1) GCM_PASS(4, 1) GCM_PASS(5, 1)
@@ -277,7 +289,7 @@ __device__ __forceinline__ void pass_dispatch(int r1, int r2, const Src &src, co
 
 // Filter the two real rows that `load(i)` delivers as re/im: forward FFT, multiply by S[n]/N
 // (n folded, low_pass.py:61-72; numpy's irfft scales by 1/N), inverse FFT, `store(i, V)`.
-template <int MAXR, typename T, typename Load, typename Store>
+template <int MAXR, unsigned MASK, typename T, typename Load, typename Store>
 __device__ __forceinline__ void filter_rows_composite(typename Vec2<T>::type *x, const Load &load, const Store &store,
                                                       const typename Vec2<T>::type *tw, const SuperPlan &P, int N,
                                                       const T *S) {
@@ -294,22 +306,22 @@ __device__ __forceinline__ void filter_rows_composite(typename Vec2<T>::type *x,
     // one loop: their global addresses would otherwise be hoisted out of it and pinned in registers
     const int np = P.npass;
     int Ns = P.r1[0] * P.r2[0];
-    pass_dispatch<MAXR, false>(P.r1[0], P.r2[0], load, lds_dst, false, tw, N, 1, P.magic[0]);
+    pass_dispatch<MAXR, MASK, false>(P.r1[0], P.r2[0], load, lds_dst, false, tw, N, 1, P.magic[0]);
     for (int pass = 1; pass < np; ++pass) {
-        pass_dispatch<MAXR, false>(P.r1[pass], P.r2[pass], lds_src, lds_dst, true, tw, N, Ns, P.magic[pass]);
+        pass_dispatch<MAXR, MASK, false>(P.r1[pass], P.r2[pass], lds_src, lds_dst, true, tw, N, Ns, P.magic[pass]);
         Ns *= P.r1[pass] * P.r2[pass];
     }
     if (np == 1) {
-        pass_dispatch<MAXR, true>(P.r1[0], P.r2[0], lds_src_filtered, store, false, tw, N, 1, P.magic[0]);
+        pass_dispatch<MAXR, MASK, true>(P.r1[0], P.r2[0], lds_src_filtered, store, false, tw, N, 1, P.magic[0]);
         return;
     }
-    pass_dispatch<MAXR, true>(P.r1[0], P.r2[0], lds_src_filtered, lds_dst, true, tw, N, 1, P.magic[0]);
+    pass_dispatch<MAXR, MASK, true>(P.r1[0], P.r2[0], lds_src_filtered, lds_dst, true, tw, N, 1, P.magic[0]);
     Ns = P.r1[0] * P.r2[0];
     for (int pass = 1; pass < np - 1; ++pass) {
-        pass_dispatch<MAXR, true>(P.r1[pass], P.r2[pass], lds_src, lds_dst, true, tw, N, Ns, P.magic[pass]);
+        pass_dispatch<MAXR, MASK, true>(P.r1[pass], P.r2[pass], lds_src, lds_dst, true, tw, N, Ns, P.magic[pass]);
         Ns *= P.r1[pass] * P.r2[pass];
     }
-    pass_dispatch<MAXR, true>(P.r1[np - 1], P.r2[np - 1], lds_src, store, false, tw, N, Ns, P.magic[np - 1]);
+    pass_dispatch<MAXR, MASK, true>(P.r1[np - 1], P.r2[np - 1], lds_src, store, false, tw, N, Ns, P.magic[np - 1]);
 }
 
 // generic path: filter two real rows held as re/im of x[0..N): FFT, multiply by S[n] (n folded),
@@ -383,6 +395,7 @@ inline void make_super_plan(int n, SuperPlan *P) {
         P->magic[P->npass] = (unsigned)(((1ULL << 32) + (unsigned long long)Ns - 1) / (unsigned long long)Ns);
         Ns *= (long)r1 * r2;
         if (r1 * r2 > P->maxr) P->maxr = r1 * r2;
+        P->mask |= pass_bit(r1, r2);
         if (n / (r1 * r2) > widest) widest = n / (r1 * r2);
         ++P->npass;
         ++lo;

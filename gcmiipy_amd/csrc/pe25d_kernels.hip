@@ -78,7 +78,7 @@ struct Idx {
 
 // ---------------------------------------------------------------- K1: spu = filter(su * iph(sp))
 constexpr int kFftThreads = 256;    // generic path; the composite path sizes the workgroup from its plan
-template <typename T, int MAXR>
+template <typename T, int MAXR, unsigned MASK = 0>
 __global__ __launch_bounds__(512) void pe_spu_filter_kernel(PeArgsT<T> a) {
     using V = typename Vec2<T>::type;
     extern __shared__ unsigned char lds_raw[];
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512) void pe_spu_filter_kernel(PeArgsT<T> a) {
     if (a.filter && W > 1) {
         if (MAXR > 0) {
             const int jg = wrapi(a.row0 + j, a.Hg);
-            filter_rows_composite<MAXR, T>(x, load, store, a.tw, a.cplan, W, a.smul + (long)jg * (W / 2 + 1));
+            filter_rows_composite<MAXR, MASK, T>(x, load, store, a.tw, a.cplan, W, a.smul + (long)jg * (W / 2 + 1));
         } else {
             for (int i = threadIdx.x; i < W; i += blockDim.x) x[i] = load(i);
             __syncthreads();
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void pe_pit_kernel(PeArgsT<T> a) {
 }
 
 // ---------------------------------------------------------------- K3: pgfu = filter(pgu + phiu)
-template <typename T, int MAXR>
+template <typename T, int MAXR, unsigned MASK = 0>
 __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
     using V = typename Vec2<T>::type;
     extern __shared__ unsigned char lds_raw[];
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
     };
     if (a.filter && W > 1) {
         if (MAXR > 0) {
-            filter_rows_composite<MAXR, T>(x, load, store, a.tw, a.cplan, W, a.smul + (long)jg * (W / 2 + 1));
+            filter_rows_composite<MAXR, MASK, T>(x, load, store, a.tw, a.cplan, W, a.smul + (long)jg * (W / 2 + 1));
         } else {
             for (int i = threadIdx.x; i < W; i += blockDim.x) x[i] = load(i);
             __syncthreads();
@@ -309,14 +309,15 @@ __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
 // ---------------------------------------------------------------- K4: update
 // One thread per (j, i) column marching up the levels: the k-1 / k / k+1 values of the stage
 // winds, theta, q and sigma-dot rotate through registers, so only the horizontal neighbours
-// are loaded per level.  Tiles (row, 256-column block) are dealt to the 8 XCDs in contiguous
+// are loaded per level.  Tiles (row, 64-column block) are dealt to the 8 XCDs in contiguous
 // runs of rows (as sw2d_fused_kernel does): the blocks resident on one XCD work on adjacent
 // rows at about the same level, so the j+-1 re-reads hit that XCD's L2.
+constexpr int kUpdThreads = 64;   // one wave per workgroup: packs the rounds of a short band best (256: +2.5 %)
 template <typename T>
-__global__ __launch_bounds__(256) void pe_update_kernel(PeArgsT<T> a) {
+__global__ __launch_bounds__(kUpdThreads) void pe_update_kernel(PeArgsT<T> a) {
     const Idx ix{a.W, a.H, a.L, a.wrap};
     const int W = a.W, L = a.L;
-    const int iblocks = (W + 255) / 256;
+    const int iblocks = (W + kUpdThreads - 1) / kUpdThreads;
     const int per_xcd = gridDim.x / 8;
     const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     // tile = ((row, level segment), column block); rows come from [j0, j1) then [jb0, jb1)
@@ -326,7 +327,7 @@ __global__ __launch_bounds__(256) void pe_update_kernel(PeArgsT<T> a) {
     const int na = a.j1 - a.j0;
     if (jrel >= na + (a.jb1 - a.jb0)) return;                // padding tiles
     const int j = jrel < na ? a.j0 + jrel : a.jb0 + (jrel - na);
-    const int i = (tile - rowseg * iblocks) * 256 + threadIdx.x;
+    const int i = (tile - rowseg * iblocks) * kUpdThreads + threadIdx.x;
     if (i >= W) return;
     const int iw = i == 0 ? W - 1 : i - 1, ie = i + 1 == W ? 0 : i + 1;
     const int jg = wrapi(a.row0 + j, a.Hg);
@@ -695,9 +696,17 @@ static size_t rows_alloc(const Pe25d *m) { return (size_t)m->H + 2 * kGhost; }
 // of small radices (1440 = 10.12.12) is not held to the register budget of a 25-point butterfly;
 // 0 = generic ping-pong passes
 template <typename T> using FilterKernel = void (*)(PeArgsT<T>);
+// plans with their own instantiation (only their passes compiled in): the row lengths of the
+// BASELINE configs and the powers of 16
+constexpr unsigned kMask1440 = pass_bit(5, 2) | pass_bit(4, 3);                    // 1440, 720, 360, 120 ...
+constexpr unsigned kMask2880 = pass_bit(5, 3) | pass_bit(4, 3) | pass_bit(4, 4);   // 2880
+constexpr unsigned kMask4096 = pass_bit(4, 4);                                     // 256, 4096
 template <typename T>
 static FilterKernel<T> spu_filter_kernel_for(const SuperPlan &P) {
     if (!P.ok) return pe_spu_filter_kernel<T, 0>;
+    if (P.mask == kMask1440) return pe_spu_filter_kernel<T, 12, kMask1440>;
+    if (P.mask == kMask2880) return pe_spu_filter_kernel<T, 16, kMask2880>;
+    if (P.mask == kMask4096) return pe_spu_filter_kernel<T, 16, kMask4096>;
     if (P.maxr <= 12) return pe_spu_filter_kernel<T, 12>;
     if (P.maxr <= 16) return pe_spu_filter_kernel<T, 16>;
     return pe_spu_filter_kernel<T, 25>;
@@ -705,6 +714,9 @@ static FilterKernel<T> spu_filter_kernel_for(const SuperPlan &P) {
 template <typename T>
 static FilterKernel<T> pgf_filter_kernel_for(const SuperPlan &P) {
     if (!P.ok) return pe_pgf_filter_kernel<T, 0>;
+    if (P.mask == kMask1440) return pe_pgf_filter_kernel<T, 12, kMask1440>;
+    if (P.mask == kMask2880) return pe_pgf_filter_kernel<T, 16, kMask2880>;
+    if (P.mask == kMask4096) return pe_pgf_filter_kernel<T, 16, kMask4096>;
     if (P.maxr <= 12) return pe_pgf_filter_kernel<T, 12>;
     if (P.maxr <= 16) return pe_pgf_filter_kernel<T, 16>;
     return pe_pgf_filter_kernel<T, 25>;
@@ -1022,8 +1034,8 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         a.j1 = std::max(r0, r1);
         a.jb0 = rb0;
         a.jb1 = std::max(rb0, rb1);
-        const long tiles = (long)((W + 255) / 256) * rows * a.nseg;
-        hipLaunchKernelGGL(pe_update_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, st, a);
+        const long tiles = (long)((W + kUpdThreads - 1) / kUpdThreads) * rows * a.nseg;
+        hipLaunchKernelGGL(pe_update_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kUpdThreads), 0, st, a);
     };
     const bool split = mode != 0 && (j1 - j0) > 2 * kGhost;
     if (mode == 0) {
