@@ -292,7 +292,7 @@ __device__ __forceinline__ void pass_dispatch(int r1, int r2, const Src &src, co
 template <int MAXR, unsigned MASK, typename T, typename Load, typename Store>
 __device__ __forceinline__ void filter_rows_composite(typename Vec2<T>::type *x, const Load &load, const Store &store,
                                                       const typename Vec2<T>::type *tw, const SuperPlan &P, int N,
-                                                      const T *S) {
+                                                      const T *S, bool load_reads_x = false) {
     using V = typename Vec2<T>::type;
     const T inv_n = T(1.0) / (T)N;
     const auto lds_src = [x](int i) { return x[i]; };
@@ -306,7 +306,7 @@ __device__ __forceinline__ void filter_rows_composite(typename Vec2<T>::type *x,
     // one loop: their global addresses would otherwise be hoisted out of it and pinned in registers
     const int np = P.npass;
     int Ns = P.r1[0] * P.r2[0];
-    pass_dispatch<MAXR, MASK, false>(P.r1[0], P.r2[0], load, lds_dst, false, tw, N, 1, P.magic[0]);
+    pass_dispatch<MAXR, MASK, false>(P.r1[0], P.r2[0], load, lds_dst, load_reads_x, tw, N, 1, P.magic[0]);
     for (int pass = 1; pass < np; ++pass) {
         pass_dispatch<MAXR, MASK, false>(P.r1[pass], P.r2[pass], lds_src, lds_dst, true, tw, N, Ns, P.magic[pass]);
         Ns *= P.r1[pass] * P.r2[pass];

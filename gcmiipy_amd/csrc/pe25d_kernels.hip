@@ -294,7 +294,12 @@ __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
     };
     if (a.filter && W > 1) {
         if (MAXR > 0) {
-            filter_rows_composite<MAXR, MASK, T>(x, load, store, a.tw, a.cplan, W, a.smul + (long)jg * (W / 2 + 1));
+            // the row goes through LDS first: the first pass would otherwise hold the ~10 loads of
+            // each of its R elements in flight at once (165 VGPRs; 122 this way: 4 waves/SIMD)
+            for (int i = threadIdx.x; i < W; i += blockDim.x) x[i] = load(i);
+            __syncthreads();
+            const auto from_x = [x](int i) { return x[i]; };
+            filter_rows_composite<MAXR, MASK, T>(x, from_x, store, a.tw, a.cplan, W, a.smul + (long)jg * (W / 2 + 1), true);
         } else {
             for (int i = threadIdx.x; i < W; i += blockDim.x) x[i] = load(i);
             __syncthreads();
