@@ -367,3 +367,33 @@ def test_band_runner_processes_one_gpu(tmp_path, model, world):
         axis = 1 if (model == "pe" and f > 0) else 0
         got = np.concatenate([p_[k] for p_ in parts], axis=axis)
         assert rel_err(got, want[f]) < 1e-13, (k, rel_err(got, want[f]))
+
+
+def test_halo_buffer_registration_errors():
+    """gcm_set_halo_buffers / gcm_wait_edges argument and state checking"""
+    import torch
+    import gcmiipy_amd as g
+    from gcmiipy_amd import geometry
+    from gcmiipy_amd.core import GcmError
+    H, W, L = 12, 16, 4
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    single = g.Core(g._lib.PE25D, W, H, L, geom=geom)
+    buf = torch.empty(1 << 16, dtype=torch.float64, device="cuda")
+    with pytest.raises(GcmError, match="not a latitude band"):
+        single.set_halo_buffers(buf.data_ptr(), buf.data_ptr())
+    single.close()
+    band = g.Core(g._lib.PE25D, W, 6, L, geom=geom, nranks=2, rank=0, global_height=H, row0=0)
+    with pytest.raises(GcmError, match="no send buffers registered"):
+        band.wait_edges(None)
+    with pytest.raises(ValueError, match="both buffers"):
+        band.set_halo_buffers(buf.data_ptr(), None)
+    band.set_halo_buffers(buf.data_ptr(), buf[1 << 15:].data_ptr())
+    band.wait_edges(None)                      # an event that was never recorded: returns at once
+    band.set_halo_buffers(None, None)          # unregister
+    with pytest.raises(GcmError, match="no send buffers registered"):
+        band.wait_edges(None)
+    band.close()
+    sw = g.Core(g._lib.SW2D, 32, 8, dx=300e3, nranks=2, rank=0, global_height=16, row0=0)
+    with pytest.raises(GcmError, match="GCM_PE25D latitude bands only"):
+        sw.set_halo_buffers(buf.data_ptr(), buf.data_ptr())
+    sw.close()
