@@ -857,14 +857,15 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
         return nullptr;
     }
     {
-        // K4 runs 2 workgroups of 256 columns per CU; a band with fewer column blocks than about
-        // four rounds of that splits the level march, so that the kernel is several short rounds
-        // instead of one or two long ones (results do not depend on the split)
+        // K4 runs 8 one-wave workgroups per CU (2 waves/SIMD); a band with fewer workgroups than
+        // about 2.5 rounds of that splits the level march, so that the kernel is several short
+        // rounds instead of one or two long ones (results do not depend on the split; measured
+        // on 1440 columns: 90 rows best with 2-3 segments, 180 with 2, 360 and more with 1)
         int dev = 0, cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        const long tiles = (long)((W + 255) / 256) * m->H;
-        long want = (4L * 2 * cus + tiles - 1) / tiles;
+        const long tiles = (long)((W + kUpdThreads - 1) / kUpdThreads) * m->H;
+        long want = (5L * 8 * cus / 2 + tiles - 1) / tiles;
         if (const char *e = getenv("GCM_PE_LEVEL_SEGMENTS")) want = atoi(e);
         const int cap = std::min(kMaxSeg, std::max(1, L / 4));
         m->nseg = (int)std::max(1L, std::min((long)cap, want));
