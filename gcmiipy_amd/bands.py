@@ -15,8 +15,9 @@ to the two ring neighbours (point-to-point, no collective on the data path).
   GCM_PE25D: TWO exchanges per step -- the predicted state before the corrector and the new
     state before the next predictor (the corrector needs the
     neighbour's *predicted* rows, which cannot be recomputed from a 2-row halo).  Each Euler
-    stage updates the two edge rows of either side first, posts their exchange, and updates
-    the interior rows meanwhile ("edge first"), so the exchange hides behind the largest kernel.
+    stage updates and packs the two edge rows of either side on the library's second stream
+    while the interior rows run on the compute stream ("edge first", gcm_set_halo_buffers);
+    the exchange is posted once both are queued and hides behind the interior rows.
 
 `BandRunner` only orchestrates; the numerical work is behind an *engine*:
 `HipBandEngine` (the product: a `Core` with nranks > 1) or, in the CPU/gloo tests,
