@@ -115,11 +115,13 @@ def test_geography_harness_h1(g):
 
 
 @pytest.mark.parametrize("hwl", [(8, 16, 4), (6, 10, 3), (5, 12, 1), (12, 20, 5), (7, 30, 2),
-                                 (3, 1440, 2), (4, 2880, 3), (3, 14, 2), (2, 2250, 1)])
+                                 (3, 1440, 2), (4, 2880, 3), (3, 14, 2), (2, 2250, 1), (3, 400, 2), (2, 1250, 1),
+                                 (2, 4096, 2)])
 def test_shapes_vs_oracle(g, hwl):
     """ragged sizes: odd L (unpaired level in the packed FFT), radix-3/5 widths, L = 1; the row
     lengths of BASELINE configs[3] / [4] (1440, 2880: in-place FFT), a radix-7 length (generic
-    butterfly, ping-pong buffers) and 2250 = 2.3.3.5.5.5, whose radix-2 pass is too wide for the in-place form"""
+    butterfly, generic ping-pong path), 2250 = 10.15.15, 400 = 20.20 and 1250 = 10.25.5 (the widest
+    composite radices), 4096 = 16.16.16"""
     from gcmiipy_amd import geometry
     from oracle import dynamics as odyn, geometry as ogeo, temperature as otemp
     H, W, L = hwl
