@@ -397,3 +397,69 @@ def test_halo_buffer_registration_errors():
     with pytest.raises(GcmError, match="GCM_PE25D latitude bands only"):
         sw.set_halo_buffers(buf.data_ptr(), buf.data_ptr())
     sw.close()
+
+
+def _rccl_self_worker(rank, port, model, outdir):
+    """one process, one GPU, the REAL backend: an RCCL ("nccl") group of one rank whose band is its
+    own north and south neighbour -- numerically the periodic single domain"""
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    import gcmiipy_amd as g
+    from gcmiipy_amd import geometry
+    from gcmiipy_amd.bands import BandRunner, HipBandEngine
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    if model == "pe":
+        H, W, L, steps, dt = 23, 36, 9, 5, 120.0
+        geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+        c = g.Core(g._lib.PE25D, W, H, L, geom=geom, nranks=2, rank=0, global_height=H, row0=0,
+                   stream=torch.cuda.current_stream().cuda_stream)
+        c.set_state(*_ic_pe(geom))
+    else:
+        H, W, steps, dt = 64, 130, 11, 300.0
+        c = g.Core(g._lib.SW2D_TEMP, W, H, dx=300e3, tracer=g._lib.TRACER_VANLEER, nranks=2, rank=0,
+                   global_height=H, row0=0, stream=torch.cuda.current_stream().cuda_stream,
+                   halo_steps=1 if model == "c3" else 4)
+        c.set_state(**_ic2d((H, W)))
+    eng = HipBandEngine(c, torch)                 # stream-aware: the exchange is ordered on streams only
+    runner = BandRunner(eng, 0, 2, dist)
+    runner.north = runner.south = 0
+    runner.run(steps, dt)
+    torch.cuda.synchronize()
+    st = c.get_state()
+    np.savez(os.path.join(outdir, "self.npz"), **{k: a for k, a in zip("puvtq", st) if a is not None})
+    c.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", ["pe", "c3", "c3deep"])
+def test_band_runner_over_rccl_self_ring(tmp_path, model):
+    """The production exchange path -- torch.distributed "nccl" = RCCL, batch_isend_irecv on the comm
+    stream, no host synchronisation -- on the one GPU of the test box: RCCL refuses two ranks per
+    device, but a rank may send to itself, and a band that is its own neighbour on both sides is
+    the periodic single domain.  Bit-identical to it (GCM_PE25D: edge rows updated and packed on
+    the library's second stream while the interior rows run)."""
+    import torch.multiprocessing as mp
+    import gcmiipy_amd as g
+    from gcmiipy_amd import geometry
+    mp.spawn(_rccl_self_worker, args=(_free_port(), model, str(tmp_path)), nprocs=1, join=True)
+    got = np.load(os.path.join(str(tmp_path), "self.npz"))
+    if model == "pe":
+        H, W, L = 23, 36, 9
+        geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+        ref = g.Core(g._lib.PE25D, W, H, L, geom=geom)
+        ref.set_state(*_ic_pe(geom))
+        ref.step(5, 120.0)
+    else:
+        H, W = 64, 130
+        ref = g.Core(g._lib.SW2D_TEMP, W, H, dx=300e3, tracer=g._lib.TRACER_VANLEER)
+        ref.set_state(**_ic2d((H, W)))
+        ref.step(11, 300.0)
+    want = ref.get_state()
+    ref.close()
+    for k, w in zip("puvtq", want):
+        assert np.array_equal(got[k], w), k
