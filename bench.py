@@ -153,7 +153,7 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
                       dtype="f32" if name.endswith("_f32") else "f64")
         core.set_state(**synth(name, H, W, L, row0, nrows, geom))
         eng = HipBandEngine(core, torch, stream_aware=cx.backend == "nccl") if world > 1 else None
-        runner = BandRunner(eng, rank, world, dist)
+        runner = BandRunner(eng, rank, world, cx.ring if world > 1 else dist)
         region = {}
 
         def run_chunk(n, timed):
@@ -236,6 +236,7 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
                "dtype": "f32" if name.endswith("_f32") else "f64",
                "bytes_per_cell_update": bpc,
                "hbm_roofline_frac_whole_job": value * bpc / (world * HBM_PEAK_GBS * 1e9),
+               "exchange": cx.exchange if world > 1 else None,
                "decomposition": "%d latitude band(s)%s" % (
                    world, ", ghost rows exchanged every %d steps" % k if world > 1 and k > 1 else "")}
         if world > 1:
@@ -333,6 +334,7 @@ def main():
         cx.local = 0
     torch.cuda.set_device(cx.local)
     cx.dist = None
+    cx.ring, cx.exchange = None, None
     cx.backend = "nccl"
     if cx.world > 1:
         import torch.distributed as dist
@@ -345,6 +347,18 @@ def main():
             cx.local = 0
             dist.init_process_group(cx.backend)
         cx.dist = dist
+        # the ghost rows go over RCCL called directly (gcmiipy_amd.rccl: the exchange kernel on the
+        # library's comm stream, a few ctypes calls per exchange); torch.distributed bootstraps it and
+        # does the barriers.  GCM_BENCH_EXCHANGE=torch keeps batch_isend_irecv.
+        cx.ring, cx.exchange = dist, "torch.distributed batch_isend_irecv (%s)" % cx.backend
+        if cx.backend == "nccl" and os.environ.get("GCM_BENCH_EXCHANGE", "rccl") == "rccl":
+            try:
+                from gcmiipy_amd.rccl import RcclP2P
+                ring = RcclP2P(dist, cx.rank, cx.world)
+                ring.self_check()
+                cx.ring, cx.exchange = ring, "RCCL ncclSend/ncclRecv groups (gcmiipy_amd.rccl)"
+            except Exception as e:          # noqa: BLE001 -- any failure: the torch path still works
+                print("bench.py: direct RCCL exchange unavailable (%s); using torch.distributed" % e, file=sys.stderr)
 
     main_res = run_workload(cx, a.workload, a.steps, a.warmup, a.variant)
     also = {}

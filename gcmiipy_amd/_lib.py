@@ -67,6 +67,7 @@ SYMBOLS = {
     "gcm_halo_pack2": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gcm_set_halo_buffers": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "gcm_wait_edges": (C.c_int, [_H, C.c_void_p]),
+    "gcm_comm_stream": (C.c_int, [_H, C.POINTER(C.c_void_p)]),
     "gcm_halo_unpack2": (C.c_int, [_H, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gcm_step_interior": (C.c_int, [_H, C.c_double, C.c_void_p]),
     "gcm_step_boundary": (C.c_int, [_H, C.c_double, C.c_void_p]),

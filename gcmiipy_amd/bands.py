@@ -195,7 +195,9 @@ class HipBandEngine:
         mk = lambda: torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
         self.sbuf, self.rbuf = [mk(), mk()], [mk(), mk()]
         self.compute = torch.cuda.current_stream()
-        self.comm = torch.cuda.Stream() if overlap else self.compute
+        # the comm stream comes from the library, which checks that it really runs beside the
+        # compute stream (two HIP streams may share a hardware queue and then run in order)
+        self.comm = torch.cuda.ExternalStream(core.comm_stream()) if overlap else self.compute
         self.overlap = overlap
         self._ctx = None
         self._packed = torch.cuda.Event()

@@ -219,6 +219,12 @@ class Core:
     def wait_edges(self, stream):
         _check(lib.gcm_wait_edges(self._h, stream), self._h)
 
+    def comm_stream(self):
+        """hipStream_t (int) of a handle-owned stream measured to run beside the compute stream"""
+        out = C.c_void_p()
+        _check(lib.gcm_comm_stream(self._h, C.byref(out)), self._h)
+        return out.value
+
     def step_interior(self, dt, stream=None):
         _check(lib.gcm_step_interior(self._h, float(dt), stream), self._h)
 

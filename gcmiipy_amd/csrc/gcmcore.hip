@@ -36,6 +36,7 @@ struct gcm_handle {
     int G = kGhost;          // ghost rows per side = 2 * steps between exchanges (2-D bands)
     int since_exchange = 0;  // steps taken on the current ghost rows
     bool star_valid = false;
+    hipStream_t comm = nullptr;       // gcm_comm_stream: owned, created on first request
     double *snap[GCM_NFIELDS] = {};   // gcm_snapshot: device copy of the state, ghost rows included
     int snap_since_exchange = 0;
     int variant = GCM_VARIANT_FUSED;
@@ -107,6 +108,10 @@ int gcm_destroy(gcm_handle *h) {
     if (!h) return GCM_OK;
     if (h->cfg.device >= 0) (void)hipSetDevice(h->cfg.device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->comm) {
+        (void)hipStreamSynchronize(h->comm);
+        (void)hipStreamDestroy(h->comm);
+    }
     if (h->pe) pe25d_destroy(h->pe);
     for (void *p : h->allocs) (void)hipFree(p);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
@@ -463,6 +468,17 @@ int gcm_step_phase(gcm_handle *h, int phase, double dt, void *stream) {
     if (!h) return GCM_ERR_ARG;
     if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_step_phase: GCM_PE25D latitude bands only");
     return pe25d_step_phase(h->pe, phase, dt, (hipStream_t)stream, &h->err);
+}
+
+int gcm_comm_stream(gcm_handle *h, void **stream) {
+    if (!h || !stream) return GCM_ERR_ARG;
+    if (!h->comm) {
+        if (h->cfg.device >= 0) HIPCHK(h, hipSetDevice(h->cfg.device));
+        h->comm = concurrent_stream(h->stream, h->pe ? pe25d_aux_stream(h->pe) : nullptr);
+        if (!h->comm) return fail(h, GCM_ERR_HIP, "gcm_comm_stream: stream creation failed");
+    }
+    *stream = (void *)h->comm;
+    return GCM_OK;
 }
 
 int gcm_set_halo_buffers(gcm_handle *h, void *north_send, void *south_send) {

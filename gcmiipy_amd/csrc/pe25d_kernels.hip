@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -807,7 +808,71 @@ static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
     return nullptr;
 }
 
-Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
+// A second stream that really runs beside `main`.  HIP maps streams onto a few hardware queues
+// round-robin; two streams on one queue execute in order, and which streams share depends on how
+// many were created before (with RCCL initialised in the process the library's second stream
+// landed on the compute stream's queue: every kernel of a stage serialised; the comm stream on it
+// made the exchange wait for the interior rows).  So: create a few candidates, run a 100 us spin
+// kernel on `main` (and `other`) and on the candidate at once, and keep the first candidate for
+// which they all overlapped.
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();          // 100 MHz
+    while (wall_clock64() - t0 < ticks) {
+    }
+}
+
+hipStream_t concurrent_stream(hipStream_t main, hipStream_t other) {
+    constexpr int kCandidates = 6;
+    constexpr long long kSpinTicks = 10000;       // 100 us
+    hipStream_t cand[kCandidates] = {};
+    hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr, ec = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess ||
+        hipEventCreate(&ec) != hipSuccess)
+        return nullptr;
+    int pick = -1, made = 0;
+    const char *vb = getenv("GCM_VERBOSE");
+    const bool verbose = vb && vb[0] == '1';
+    for (int c = 0; c < kCandidates && pick < 0; ++c) {
+        if (hipStreamCreateWithFlags(&cand[c], hipStreamNonBlocking) != hipSuccess) break;
+        ++made;
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipStreamSynchronize(main);
+            if (other) (void)hipStreamSynchronize(other);
+            (void)hipStreamSynchronize(cand[c]);
+            (void)hipEventRecord(e0, main);
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, main, kSpinTicks);
+            if (other) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, other, kSpinTicks);
+            hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, cand[c], kSpinTicks);
+            (void)hipEventRecord(ea, main);
+            if (other) (void)hipEventRecord(ec, other);
+            (void)hipEventRecord(eb, cand[c]);
+            (void)hipStreamSynchronize(main);
+            if (other) (void)hipStreamSynchronize(other);
+            (void)hipStreamSynchronize(cand[c]);
+            float ta = 0.f, tb = 0.f, tc = 0.f;
+            (void)hipEventElapsedTime(&ta, e0, ea);
+            (void)hipEventElapsedTime(&tb, e0, eb);
+            if (other) (void)hipEventElapsedTime(&tc, e0, ec);
+            best = std::min(best, std::max(ta, std::max(tb, tc)));
+        }
+        if (verbose) fprintf(stderr, "gcmcore: stream candidate %d: the 100 us spins took %.1f us\n", c, best * 1e3f);
+        if (best < 0.16f) pick = c;               // all spins inside 160 us: they overlapped
+    }
+    if (pick < 0 && made > 0) pick = 0;           // none overlaps: still correct, only serialised
+    for (int c = 0; c < made; ++c)
+        if (c != pick) (void)hipStreamDestroy(cand[c]);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    (void)hipEventDestroy(ec);
+    if (verbose) fprintf(stderr, "gcmcore: picked stream candidate %d of %d\n", pick, made);
+    return pick >= 0 ? cand[pick] : nullptr;
+}
+
+hipStream_t pe25d_aux_stream(const Pe25d *m) { return m->aux; }
+
+Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string *err) {
     if (!cfg.dx_j || !cfg.dx_h || !cfg.sig || !cfg.dsig || !cfg.sigb || !cfg.sigt) {
         *err = "GCM_PE25D: geometry tables (dx_j, dx_h, sig, dsig, sigb, sigt) are required";
         return nullptr;
@@ -878,8 +943,10 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t, std::string *err) {
     const char *no_aux = getenv("GCM_PE_SINGLE_STREAM");      // diagnostic: one chain, one stream
     // a plain stream: a high-priority one finished the edge rows earlier, but in some processes
     // (depending on how many streams existed before) the whole step then ran at half speed
-    if (!(no_aux && no_aux[0] == '1') && hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking) != hipSuccess)
-        return bad("second stream");
+    if (!(no_aux && no_aux[0] == '1')) {
+        m->aux = concurrent_stream(main_stream, nullptr);
+        if (!m->aux) return bad("second stream");
+    }
     if (hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_a, hipEventDisableTiming) != hipSuccess ||

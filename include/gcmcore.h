@@ -212,6 +212,10 @@ int gcm_step_phase(gcm_handle *h, int phase, double dt, void *stream);
  * call is needed for those phases.  gcm_wait_edges makes a stream (the one the send is posted on)
  * wait for that pack.  NULL, NULL unregisters.                                                  */
 int gcm_set_halo_buffers(gcm_handle *h, void *north_send, void *south_send);
+/* A stream for the exchange, owned by the handle (created on first request): HIP maps streams onto a
+ * few hardware queues and two streams on one queue run in order, so the library hands out one that
+ * it has measured to run beside the handle's stream (and its internal second stream).            */
+int gcm_comm_stream(gcm_handle *h, void **stream);
 int gcm_wait_edges(gcm_handle *h, void *stream);
 
 int gcm_sync(gcm_handle *h);

@@ -155,3 +155,19 @@ def test_banded_pe25d_equals_single_domain(tmp_path, world, edge_first):
     for k, want in zip("puvtq", st):
         got = np.concatenate([pp[k] for pp in parts], axis=0 if k == "p" else 1)
         assert np.array_equal(got, want), k
+
+
+def test_rccl_unique_id_survives_transport():
+    """gcmiipy_amd.rccl carries the 128-byte ncclUniqueId from rank 0 to the others as bytes: the id
+    has NUL bytes inside, all 128 must arrive (no GPU, no librccl needed)"""
+    import ctypes as C
+    from gcmiipy_amd import rccl
+    uid = rccl._UniqueId()
+    raw = bytes((7 * i) % 256 if i % 5 else 0 for i in range(128))
+    C.memmove(C.addressof(uid), raw, 128)
+    wire = rccl.uid_to_bytes(uid)
+    assert wire == raw and len(wire) == 128
+    back = rccl.uid_from_bytes(wire)
+    assert rccl.uid_to_bytes(back) == raw
+    with pytest.raises(ValueError):
+        rccl.uid_from_bytes(raw[:100])

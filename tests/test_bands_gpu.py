@@ -412,7 +412,14 @@ def _rccl_self_worker(rank, port, model, outdir):
     from gcmiipy_amd.bands import BandRunner, HipBandEngine
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
+    direct = model.endswith("-direct")          # gcmiipy_amd.rccl: RCCL called through ctypes
+    model = model.split("-")[0]
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    if direct:
+        from gcmiipy_amd.rccl import RcclP2P
+        ring = RcclP2P(None, 0, 1)
+    else:
+        ring = dist
     if model == "pe":
         H, W, L, steps, dt = 23, 36, 9, 5, 120.0
         geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
@@ -426,28 +433,32 @@ def _rccl_self_worker(rank, port, model, outdir):
                    halo_steps=1 if model == "c3" else 4)
         c.set_state(**_ic2d((H, W)))
     eng = HipBandEngine(c, torch)                 # stream-aware: the exchange is ordered on streams only
-    runner = BandRunner(eng, 0, 2, dist)
+    runner = BandRunner(eng, 0, 2, ring)
     runner.north = runner.south = 0
     runner.run(steps, dt)
     torch.cuda.synchronize()
     st = c.get_state()
     np.savez(os.path.join(outdir, "self.npz"), **{k: a for k, a in zip("puvtq", st) if a is not None})
     c.close()
+    if direct:
+        ring.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model", ["pe", "c3", "c3deep"])
+@pytest.mark.parametrize("model", ["pe-direct", "c3-direct", "c3deep-direct", "pe", "c3deep"])
 def test_band_runner_over_rccl_self_ring(tmp_path, model):
-    """The production exchange path -- torch.distributed "nccl" = RCCL, batch_isend_irecv on the comm
-    stream, no host synchronisation -- on the one GPU of the test box: RCCL refuses two ranks per
-    device, but a rank may send to itself, and a band that is its own neighbour on both sides is
-    the periodic single domain.  Bit-identical to it (GCM_PE25D: edge rows updated and packed on
-    the library's second stream while the interior rows run)."""
+    """The production exchange paths on the one GPU of the test box -- RCCL called directly
+    (gcmiipy_amd.rccl: ncclSend/ncclRecv groups on the library's comm stream; what bench.py uses)
+    and through torch.distributed "nccl" (batch_isend_irecv) -- with no host synchronisation.  RCCL
+    refuses two ranks per device, but a rank may send to itself, and a band that is its own
+    neighbour on both sides is the periodic single domain.  Bit-identical to it (GCM_PE25D: edge
+    rows updated and packed on the library's second stream while the interior rows run)."""
     import torch.multiprocessing as mp
     import gcmiipy_amd as g
     from gcmiipy_amd import geometry
     mp.spawn(_rccl_self_worker, args=(_free_port(), model, str(tmp_path)), nprocs=1, join=True)
     got = np.load(os.path.join(str(tmp_path), "self.npz"))
+    model = model.split("-")[0]
     if model == "pe":
         H, W, L = 23, 36, 9
         geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)

@@ -26,6 +26,10 @@ def main():
     ap.add_argument("--splits", default="1,2,4,8")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--exchange", default="local", choices=["local", "rccl", "torch-nccl"],
+                    help="local: device copy in place of the exchange; rccl: the band sends to itself through "
+                         "gcmiipy_amd.rccl (RCCL called directly: the production path, no xGMI); torch-nccl: the "
+                         "same through torch.distributed's batch_isend_irecv")
     a = ap.parse_args()
     import torch
     import bench
@@ -33,6 +37,15 @@ def main():
     from gcmiipy_amd import _lib, geometry
     from gcmiipy_amd.bands import BandRunner, HipBandEngine, LoopbackExchange as LoopbackDist, split_rows
     torch.cuda.set_device(0)
+    tdist = None
+    if a.exchange == "torch-nccl":
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    elif a.exchange == "rccl":
+        from gcmiipy_amd.rccl import RcclP2P
+        tdist = RcclP2P(None, 0, 1)
     _shift = [torch.cuda.Stream() for _ in range(int(os.environ.get("GCM_TEST_STREAM_SHIFT", "0")))]
     for st in _shift:
         with torch.cuda.stream(st):
@@ -55,7 +68,9 @@ def main():
         if model != "PE25D":
             core.snapshot()
         eng = HipBandEngine(core, torch) if n > 1 else None
-        runner = BandRunner(eng, rank, n, LoopbackDist() if n > 1 else None)
+        runner = BandRunner(eng, rank, n, (tdist if tdist is not None else LoopbackDist()) if n > 1 else None)
+        if tdist is not None:
+            runner.north = runner.south = 0
         if n == 1:
             runner.e = type("E", (), {"step_all": staticmethod(lambda dt_: core.step(1, dt_))})()
         import time
@@ -100,8 +115,9 @@ def main():
     for r in res:
         if base:
             r["compute_bound_speedup"] = base / r["ms_per_step"]
-    doc = {"workload": desc, "note": "one band of an N-way split stepped on one GPU, exchange replaced by a "
-           "device-local copy: the kernels' own strong-scaling bound", "bands": res}
+    doc = {"workload": desc, "exchange": a.exchange,
+           "note": "one band of an N-way split stepped on one GPU, exchange replaced by a device-local copy "
+                   "(local) or sent to itself through RCCL (rccl): the kernels' own strong-scaling bound", "bands": res}
     print(json.dumps(doc))
     if a.out:
         with open(os.path.join(ROOT, a.out), "w") as f:

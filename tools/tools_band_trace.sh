@@ -1,10 +1,10 @@
 #!/bin/bash
-# kernel trace of one band of an N-way split: bash tools_band_trace.sh <tag> <workload> <N>
-TAG=$1; WL=$2; N=$3
+# kernel trace of one band of an N-way split: bash tools_band_trace.sh <tag> <workload> <N> [local|rccl]
+TAG=$1; WL=$2; N=$3; EX=${4:-local}
 OUT=/root/repo/gpurun_out/bandtrace_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 /root/repo/tools/tools_band_time.py --workload $WL --splits $N --steps 10 > $OUT/out.txt 2> $OUT/err.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 /root/repo/tools/tools_band_time.py --workload $WL --splits $N --steps 10 --exchange $EX > $OUT/out.txt 2> $OUT/err.txt
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/*/*_kernel_trace.csv")[0]
@@ -13,6 +13,6 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 k = [i for i, r in enumerate(rows) if "spu_filter" in r["Kernel_Name"] or "fused" in r["Kernel_Name"]]
 i0 = k[len(k) // 2]
 t0 = int(rows[i0]["Start_Timestamp"])
-for r in rows[i0:i0 + 26]:
+for r in rows[i0:i0 + 30]:
     print("%-34s q=%s start %8.1f end %8.1f dur %7.1f us grid %s" % (r["Kernel_Name"].replace("void gcm::", "")[:34], r.get("Queue_Id"), (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size_X", r.get("Grid_Size"))))
 PY
