@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -424,7 +425,23 @@ int gcm_step(gcm_handle *h, int nsteps, double dt) {
     if (!h->wrap && h->since_exchange + nsteps > h->G / kGhost)
         return fail(h, GCM_ERR_STATE,
                     "gcm_step: a latitude band needs a ghost-row exchange every halo_steps steps");
-    for (int n = 0; n < nsteps; ++n) {
+    int n0 = 0;
+    if (h->cfg.model == GCM_SW2D && h->wrap && h->variant == GCM_VARIANT_FUSED && !h->timing &&
+        !(getenv("GCM_SW2D_TWO_STEP") && getenv("GCM_SW2D_TWO_STEP")[0] == '0')) {
+        // small grids: pairs of steps in one launch (sw2d_fused2_kernel)
+        while (nsteps - n0 >= 2) {
+            Sw2dArgs a = base_args(h, dt);
+            a.ou = h->nxt[GCM_U];
+            a.ov = h->nxt[GCM_V];
+            a.op = h->nxt[GCM_P];
+            a.j0 = 0;
+            a.j1 = h->H;
+            if (!launch_sw2d_fused2(a, h->stream)) break;
+            swap_state(h);
+            n0 += 2;
+        }
+    }
+    for (int n = n0; n < nsteps; ++n) {
         // bands: each step consumes two ghost rows per side; the rows still valid shrink towards
         // the interior until the next exchange (communication-avoiding deep halo)
         const int e = h->wrap ? 0 : h->G - kGhost * (h->since_exchange + 1);

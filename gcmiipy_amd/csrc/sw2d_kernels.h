@@ -35,6 +35,8 @@ void launch_tracer_axis(const Sw2dArgs &a, int axis, bool limit, const double *q
 // fused variant: predictor + corrector (+ both tracer passes) in one launch
 void launch_sw2d_fused(const Sw2dArgs &a, bool temp, int tracer, hipStream_t s);
 int sw2d_fused_rows_per_band(int W, int H, bool temp, int tracer, bool wrap);
+// GCM_SW2D, single band, short bands (small grids): TWO steps in one launch; false if not applicable
+bool launch_sw2d_fused2(const Sw2dArgs &a, hipStream_t s);
 
 // GCM_PE2D: one Euler stage; base/stage/out are {p,u,v,t,q} interior pointers (wrap only)
 void launch_pe2d_stage(const double *const base[5], const double *const stage[5], double *const out[5],

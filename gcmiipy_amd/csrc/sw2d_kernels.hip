@@ -388,6 +388,134 @@ __global__ __launch_bounds__(64) void sw2d_fused_kernel(Sw2dArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ two steps per launch
+// Plain shallow water on a small grid (720x360) is bound by one dependent launch per step (about
+// 2.3 of 5.7 us) plus one wait for memory.  This kernel does TWO Matsuno steps per launch: a second
+// pipeline of the same row-march consumes the rows of the first as they leave its corrector, three
+// rows behind, and only its results go to memory.  Per step the halo grows by two cells each way:
+// 56 of the 64 lanes and RPB of the RPB + 4 first-step rows are output.  Rows of the band are all
+// loaded up front (compile-time indexed), the iterations are unrolled with both windows rotated by
+// name.  Periodic rows only (a single band).
+constexpr int kStrip2Cols = 56;
+
+struct Out3 {
+    double u, v, p;
+};
+
+// predictor for row r from base rows (BM, B0, BP) into SN; corrector for row r - 1 from the
+// predicted rows (SM, S0, SN) and base row BM if `corr`
+__device__ __forceinline__ Out3 matsuno_row(bool corr, const Row &BM, const Row &B0, const Row &BP, Row &SN,
+                                            const Row &SM, const Row &S0, double dt, double g_dx, double h_dx) {
+    {
+        const Tend t = tendencies<false>(BM, B0, BP, g_dx, h_dx, 0.0);
+        make_row<false>(SN, B0.u - dt * t.du, B0.v - dt * t.dv, B0.p - dt * t.dp, 0.0, nullptr);
+    }
+    Out3 o{0.0, 0.0, 0.0};
+    if (corr) {
+        const Tend t = tendencies<false>(SM, S0, SN, g_dx, h_dx, 0.0);
+        o.u = BM.u - dt * t.du;
+        o.v = BM.v - dt * t.dv;
+        o.p = BM.p - dt * t.dp;
+    }
+    return o;
+}
+
+struct Fused2Ctx {
+    const Sw2dArgs &a;
+    int ja, jb, col;
+    bool store_lane;
+};
+
+// iteration N of RPB + 7: first-step row r1 = ja - 3 + N, second-step row r2 = r1 - 3.
+// (A1..Z1) and (A2..Z2) arrive rotated: A* is the slot of the oldest base row.
+template <int N, int RPB>
+__device__ __forceinline__ void fused2_iters(const Fused2Ctx &c, const Raw (&pre)[RPB + 8], Row &A1, Row &B1, Row &C1,
+                                             Row &X1, Row &Y1, Row &Z1, Row &A2, Row &B2, Row &C2, Row &X2, Row &Y2,
+                                             Row &Z2) {
+    if constexpr (N < RPB + 7) {
+        const double dt = c.a.dt, g_dx = c.a.g_dx, h_dx = c.a.h_dx;
+        const int r1 = c.ja - 3 + N;
+        Out3 o1{0.0, 0.0, 0.0};
+        if (r1 <= c.jb + 2) {
+            // first step: predicted row r1; its output row r1 - 1 once the window is primed (N >= 2)
+            o1 = matsuno_row(N >= 2, A1, B1, C1, X1, Y1, Z1, dt, g_dx, h_dx);
+            if constexpr (N + 3 < RPB + 8) make_row<false>(A1, pre[N + 3].u, pre[N + 3].v, pre[N + 3].p, 0.0, nullptr);  // row r1 + 2
+        }
+        if constexpr (N >= 5) {
+            // second step on the first step's rows: predicted row r2, output row r2 - 1 (N >= 7)
+            const int r2 = r1 - 3;
+            if (r2 <= c.jb) {
+                const Out3 o2 = matsuno_row(N >= 7, A2, B2, C2, X2, Y2, Z2, dt, g_dx, h_dx);
+                if (N >= 7 && r2 - 1 < c.jb && c.store_lane) {
+                    const long o = (long)(r2 - 1) * c.a.W + c.col;
+                    c.a.ou[o] = o2.u;
+                    c.a.ov[o] = o2.v;
+                    c.a.op[o] = o2.p;
+                }
+            }
+        }
+        // the first step's row r1 - 1 enters the second window: rows ja-2, ja-1, ja prime it
+        // (N = 2, 3, 4), later ones replace its oldest row
+        if constexpr (N >= 2) make_row<false>(A2, o1.u, o1.v, o1.p, 0.0, nullptr);
+        // rotate: pipeline 1 by one slot; pipeline 2 likewise once it runs or is being primed
+        if constexpr (N >= 2)
+            fused2_iters<N + 1, RPB>(c, pre, B1, C1, A1, Y1, Z1, X1, B2, C2, A2, Y2, Z2, X2);
+        else
+            fused2_iters<N + 1, RPB>(c, pre, B1, C1, A1, Y1, Z1, X1, A2, B2, C2, X2, Y2, Z2);
+    }
+}
+
+template <int RPB>
+__global__ __launch_bounds__(64) void sw2d_fused2_kernel(Sw2dArgs a) {
+    const int W = a.W, H = a.H;
+    const int lane = threadIdx.x;
+    const int strips = (W + kStrip2Cols - 1) / kStrip2Cols;
+    const int per_xcd = gridDim.x / 8;
+    const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    const int band = tile / strips;
+    const int i0 = (tile - band * strips) * kStrip2Cols;
+    Fused2Ctx c{a};
+    c.ja = a.j0 + band * RPB;
+    c.jb = min(c.ja + RPB, a.j1);
+    if (c.ja >= c.jb) return;
+    c.col = i0 - 4 + lane;
+    int ci = c.col % W;
+    if (ci < 0) ci += W;
+    c.store_lane = lane >= 4 && lane < 60 && c.col < W;
+    Raw pre[RPB + 8];                         // rows ja - 4 .. ja + RPB + 3, periodic in j
+#pragma unroll
+    for (int n = 0; n < RPB + 8; ++n) {
+        int j = (c.ja - 4 + n) % H;
+        if (j < 0) j += H;
+        const long o = (long)j * W + ci;
+        pre[n].u = a.bu[o];
+        pre[n].v = a.bv[o];
+        pre[n].p = a.bp[o];
+        pre[n].t = 0.0;
+        pre[n].q = 0.0;
+    }
+    Row A1, B1, C1, X1, Y1, Z1, A2, B2, C2, X2, Y2, Z2;
+    make_row<false>(A1, pre[0].u, pre[0].v, pre[0].p, 0.0, nullptr);
+    make_row<false>(B1, pre[1].u, pre[1].v, pre[1].p, 0.0, nullptr);
+    make_row<false>(C1, pre[2].u, pre[2].v, pre[2].p, 0.0, nullptr);
+    X1 = Y1 = Z1 = A2 = B2 = C2 = X2 = Y2 = Z2 = A1;       // overwritten before first use
+    fused2_iters<0, RPB>(c, pre, A1, B1, C1, X1, Y1, Z1, A2, B2, C2, X2, Y2, Z2);
+}
+
+// two Matsuno steps of GCM_SW2D in one launch; needs wrap_j, rows_per_band in 2..4
+bool launch_sw2d_fused2(const Sw2dArgs &a, hipStream_t s) {
+    if (!a.wrap_j || a.j0 != 0 || a.j1 != a.H || a.rows_per_band < 2 || a.rows_per_band > 4) return false;
+    const int strips = (a.W + kStrip2Cols - 1) / kStrip2Cols;
+    const int bands = (a.H + a.rows_per_band - 1) / a.rows_per_band;
+    dim3 g((unsigned)(((long)strips * bands + 7) / 8 * 8));
+    Sw2dArgs arg = a;
+    void *params[] = {&arg};
+    const void *fn = a.rows_per_band == 2 ? (const void *)sw2d_fused2_kernel<2>
+                   : a.rows_per_band == 3 ? (const void *)sw2d_fused2_kernel<3>
+                                          : (const void *)sw2d_fused2_kernel<4>;
+    return hipLaunchKernel(fn, g, dim3(64), params, 0, s) == hipSuccess;
+}
+
 constexpr int kPreloadRows = 4;     // bands of up to this many rows use the preloading variant (plain SW2D)
 
 template <bool TEMP, int TRACER>
