@@ -268,6 +268,9 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
             if model == "PE25D":
                 # pe_update_kernel runs once per Euler stage: half of the step's algorithmic bytes
                 kname, kms, launches = "pe_update_kernel", kiso, 2
+            elif variant == "fused" and model == "SW2D":
+                # plain shallow water steps in pairs (one launch = two steps): per-step figures
+                kname, kms = "sw2d_fused2_kernel (two steps per launch; per step)", region["ms"] / steps
             elif variant == "fused":
                 kname, kms = "sw2d_fused_kernel", region["ms"] / steps
             else:
