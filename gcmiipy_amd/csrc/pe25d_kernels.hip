@@ -143,11 +143,14 @@ __device__ __forceinline__ T sd_of(T rc, T pit, T sgb) { return fma(-pit, sgb, r
 // The per-level stp that phi needs after the column sum is parked in LDS, park[k][thread],
 // instead of a round trip through HBM.
 constexpr int kColThreads = 128;
-template <typename T>
+// LMAX > 0: L <= LMAX and the per-level stp stay in registers (loops unrolled over LMAX; no LDS
+// park, so the occupancy is not limited by it); LMAX == 0: any L, stp parked in LDS
+template <typename T, int LMAX = 0>
 __global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
     __shared__ double tab[kExnerTabDoubles];
     extern __shared__ unsigned char park_raw[];
-    T *park = (T *)park_raw;                    // [L][kColThreads]
+    T *park = (T *)park_raw;                    // [L][kColThreads] (LMAX == 0)
+    T stp_reg[LMAX > 0 ? LMAX : 1];
     for (int n = threadIdx.x; n < kExnerTabDoubles; n += kColThreads) tab[n] = a.exner_tab[n];
     __syncthreads();
     const Idx ix{a.W, a.H, a.L, a.wrap};
@@ -171,8 +174,9 @@ __global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
     T ex_k = exner(spc * a.sig[0] + a.ptop, tab);
     const T t0 = t_k, ex0 = ex_k;                       // level 0, for the k wrap at the top
     T acc = T(0.0);
-#pragma unroll 6
-    for (int k = 0; k < L; ++k) {
+#pragma unroll(LMAX > 0 ? LMAX : 6)
+    for (int k = 0; k < (LMAX > 0 ? LMAX : L); ++k) {
+        if (LMAX > 0 && k >= L) break;
         const long o = c3 + (long)k * W + i;
         const T tp = spc * a.sig[k] + a.ptop;
         T t_n, ex_n;
@@ -190,14 +194,17 @@ __global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
         const T stp = T(kCp) * ((t_k + t_n) * T(0.5)) * (ex_k - ex_n);
         const T s2 = a.sigt[k] * stp;
         acc += s1 - s2;
-        pk[k * kColThreads] = stp;
+        if (LMAX > 0) stp_reg[k] = stp;
+        else pk[k * kColThreads] = stp;
         t_k = t_n;
         ex_k = ex_n;
     }
     T run = acc + hmG;                                  // stp_n[0], dynamics.py:132
     a.phi[c3 + i] = run;
-    for (int k = 1; k < L; ++k) {                            // phi = cumsum(stp_n), stp_n = km(stp)
-        run += pk[(k - 1) * kColThreads];
+#pragma unroll(LMAX > 0 ? LMAX : 1)
+    for (int k = 1; k < (LMAX > 0 ? LMAX : L); ++k) {        // phi = cumsum(stp_n), stp_n = km(stp)
+        if (LMAX > 0 && k >= L) break;
+        run += LMAX > 0 ? stp_reg[k - 1] : pk[(k - 1) * kColThreads];
         a.phi[c3 + (long)k * W + i] = run;
     }
 }
@@ -802,7 +809,7 @@ static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
                             (int)filter_lds_bytes<T>(m)) != hipSuccess ||
         hipFuncSetAttribute((const void *)pgf_filter_kernel_for<T>(m->cplan), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)filter_lds_bytes<T>(m)) != hipSuccess ||
-        hipFuncSetAttribute((const void *)pe_geopot_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void *)pe_geopot_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(L * kColThreads * sizeof(T))) != hipSuccess)
         return "dynamic LDS size";
     return nullptr;
@@ -1084,8 +1091,10 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         a.j1 = j1 + ext;
         {
             const long tiles = (long)((W + kColThreads - 1) / kColThreads) * (a.j1 - a.j0);
-            hipLaunchKernelGGL(pe_geopot_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kColThreads),
-                               sizeof(T) * (size_t)L * kColThreads, s2, a);
+            const dim3 gg((unsigned)((tiles + 7) / 8 * 8));
+            if (L <= 24) hipLaunchKernelGGL((pe_geopot_kernel<T, 24>), gg, dim3(kColThreads), 0, s2, a);
+            else if (L <= 40) hipLaunchKernelGGL((pe_geopot_kernel<T, 40>), gg, dim3(kColThreads), 0, s2, a);
+            else hipLaunchKernelGGL((pe_geopot_kernel<T, 0>), gg, dim3(kColThreads), sizeof(T) * (size_t)L * kColThreads, s2, a);
         }
         hipLaunchKernelGGL(spu_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, s, a);
         {
