@@ -170,7 +170,14 @@ __global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
     const long c3 = ix.r3(j);
     // ---- compute_geopotential, dynamics.py:111-143
     const T hmG = a.heightmap ? a.heightmap[(long)jg * W + i] * T(kG) : T(0.0) * T(kG);
-    T t_k = a.st[c3 + i];
+    // LMAX > 0: the whole theta column is requested before any of it is used (one HBM latency per
+    // column instead of one per level)
+    T tcol[LMAX > 0 ? LMAX : 1];
+    if (LMAX > 0) {
+#pragma unroll
+        for (int k = 0; k < LMAX; ++k) tcol[k] = k < L ? a.st[c3 + (long)k * W + i] : T(0.0);
+    }
+    T t_k = LMAX > 0 ? tcol[0] : a.st[c3 + i];
     T ex_k = exner(spc * a.sig[0] + a.ptop, tab);
     const T t0 = t_k, ex0 = ex_k;                       // level 0, for the k wrap at the top
     T acc = T(0.0);
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
         const T tp = spc * a.sig[k] + a.ptop;
         T t_n, ex_n;
         if (k + 1 < L) {
-            t_n = a.st[o + W];
+            t_n = LMAX > 0 ? tcol[k + 1 < LMAX ? k + 1 : 0] : a.st[o + W];
             ex_n = exner(spc * a.sig[k + 1] + a.ptop, tab);
         } else {
             t_n = t0;            // kp() wraps to the bottom layer, coordinates_3d.py:55-56
