@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void pe_pit_kernel(PeArgsT<T> a) {
     const T jph_c = (spc + sps) * T(0.5), jph_n = (spn + spc) * T(0.5);  // jph(sp) at j, j-1
     const long c3 = ix.r3(j), n3 = ix.r3(j - 1);
     T pit = T(0.0);
-#pragma unroll 4
+#pragma unroll 12
     for (int k = 0; k < L; ++k) {
         const long o = c3 + (long)k * W;
         const T spv_c = a.sv[o + i] * jph_c;
