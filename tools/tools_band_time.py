@@ -46,10 +46,6 @@ def main():
     elif a.exchange == "rccl":
         from gcmiipy_amd.rccl import RcclP2P
         tdist = RcclP2P(None, 0, 1)
-    _shift = [torch.cuda.Stream() for _ in range(int(os.environ.get("GCM_TEST_STREAM_SHIFT", "0")))]
-    for st in _shift:
-        with torch.cuda.stream(st):
-            torch.zeros(1, device="cuda")
     desc, H, W, L, model, tracer, bpc, dt = bench.WORKLOADS[a.workload]
     geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig) if model == "PE25D" else None
     full = bench.synth(a.workload, H, W, L, geom=geom)
