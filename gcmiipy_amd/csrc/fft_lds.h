@@ -189,36 +189,69 @@ __device__ __forceinline__ void butterfly(V (&v)[R]) {
     }
 }
 
-// R-point DFT of v[m], m = R2 m1 + m2, result v[q], q = q1 + R1 q2:
-//   W_R^(m q) = W_R1^(m1 q1) . W_R^(m2 q1) . W_R2^(m2 q2);   W_R^t = tw[t * wstep], wstep = N / R
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+constexpr int inv_mod(int a, int n) {               // a^-1 mod n (n small), 0 if none
+    for (int t = 1; t < n; ++t)
+        if ((a * t) % n == 1) return t;
+    return n == 1 ? 0 : 0;
+}
+
+// R-point DFT of v[m] in place, R = R1 R2.
+//  * R1, R2 coprime (10 = 5.2, 12 = 4.3, 15, 20, 6): Good-Thomas.  With m = (R2 m1 + R1 m2) mod R
+//    and q = (c1 q1 + c2 q2) mod R, c1 = R2 (R2^-1 mod R1), c2 = R1 (R1^-1 mod R2), the kernel
+//    factors exactly, W_R^(m q) = W_R1^(m1 q1) W_R2^(m2 q2): no twiddles between the two stages.
+//  * otherwise (8, 9, 16, 25): Cooley-Tukey, m = R2 m1 + m2, q = q1 + R1 q2,
+//    W_R^(m q) = W_R1^(m1 q1) . W_R^(m2 q1) . W_R2^(m2 q2);   W_R^t = tw[t * wstep], wstep = N / R
 template <int R1, int R2, bool INV, typename V>
 __device__ __forceinline__ void dft_composite(V (&v)[R1 * R2], const V *tw, int wstep) {
+    constexpr int R = R1 * R2;
     if constexpr (R2 == 1) {
         butterfly<R1, INV>(v);
+    } else if constexpr (cgcd(R1, R2) == 1) {
+        constexpr int c1 = R2 * inv_mod(R2 % R1, R1), c2 = R1 * inv_mod(R1 % R2, R2);
+        V a[R];                                        // a[q1 R2 + m2]
+#pragma unroll
+        for (int m2 = 0; m2 < R2; ++m2) {
+            V t[R1];
+#pragma unroll
+            for (int m1 = 0; m1 < R1; ++m1) t[m1] = v[(R2 * m1 + R1 * m2) % R];
+            butterfly<R1, INV>(t);
+#pragma unroll
+            for (int q1 = 0; q1 < R1; ++q1) a[q1 * R2 + m2] = t[q1];
+        }
+#pragma unroll
+        for (int q1 = 0; q1 < R1; ++q1) {
+            V t[R2];
+#pragma unroll
+            for (int m2 = 0; m2 < R2; ++m2) t[m2] = a[q1 * R2 + m2];
+            butterfly<R2, INV>(t);
+#pragma unroll
+            for (int q2 = 0; q2 < R2; ++q2) v[(c1 * q1 + c2 * q2) % R] = t[q2];
+        }
     } else {
-    V a[R1 * R2];                                  // a[q1 R2 + m2]
+        V a[R];                                        // a[q1 R2 + m2]
 #pragma unroll
-    for (int m2 = 0; m2 < R2; ++m2) {
-        V t[R1];
+        for (int m2 = 0; m2 < R2; ++m2) {
+            V t[R1];
 #pragma unroll
-        for (int m1 = 0; m1 < R1; ++m1) t[m1] = v[R2 * m1 + m2];
-        butterfly<R1, INV>(t);
+            for (int m1 = 0; m1 < R1; ++m1) t[m1] = v[R2 * m1 + m2];
+            butterfly<R1, INV>(t);
 #pragma unroll
-        for (int q1 = 0; q1 < R1; ++q1) a[q1 * R2 + m2] = t[q1];
-    }
+            for (int q1 = 0; q1 < R1; ++q1) a[q1 * R2 + m2] = t[q1];
+        }
 #pragma unroll
-    for (int q1 = 1; q1 < R1; ++q1)
+        for (int q1 = 1; q1 < R1; ++q1)
 #pragma unroll
-        for (int m2 = 1; m2 < R2; ++m2) a[q1 * R2 + m2] = cmul(a[q1 * R2 + m2], twid<INV>(tw, (m2 * q1) * wstep));
+            for (int m2 = 1; m2 < R2; ++m2) a[q1 * R2 + m2] = cmul(a[q1 * R2 + m2], twid<INV>(tw, (m2 * q1) * wstep));
 #pragma unroll
-    for (int q1 = 0; q1 < R1; ++q1) {
-        V t[R2];
+        for (int q1 = 0; q1 < R1; ++q1) {
+            V t[R2];
 #pragma unroll
-        for (int m2 = 0; m2 < R2; ++m2) t[m2] = a[q1 * R2 + m2];
-        butterfly<R2, INV>(t);
+            for (int m2 = 0; m2 < R2; ++m2) t[m2] = a[q1 * R2 + m2];
+            butterfly<R2, INV>(t);
 #pragma unroll
-        for (int q2 = 0; q2 < R2; ++q2) v[q1 + R1 * q2] = t[q2];
-    }
+            for (int q2 = 0; q2 < R2; ++q2) v[q1 + R1 * q2] = t[q2];
+        }
     }
 }
 
