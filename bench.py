@@ -337,7 +337,7 @@ def main():
         cx.local = 0
     torch.cuda.set_device(cx.local)
     cx.dist = None
-    cx.ring, cx.exchange = None, None
+    cx.ring, cx.exchange, cx.stuck = None, None, False
     cx.backend = "nccl"
     if cx.world > 1:
         import torch.distributed as dist
@@ -355,13 +355,33 @@ def main():
         # does the barriers.  GCM_BENCH_EXCHANGE=torch keeps batch_isend_irecv.
         cx.ring, cx.exchange = dist, "torch.distributed batch_isend_irecv (%s)" % cx.backend
         if cx.backend == "nccl" and os.environ.get("GCM_BENCH_EXCHANGE", "rccl") == "rccl":
-            try:
-                from gcmiipy_amd.rccl import RcclP2P
-                ring = RcclP2P(dist, cx.rank, cx.world)
-                ring.self_check()
-                cx.ring, cx.exchange = ring, "RCCL ncclSend/ncclRecv groups (gcmiipy_amd.rccl)"
-            except Exception as e:          # noqa: BLE001 -- any failure: the torch path still works
-                print("bench.py: direct RCCL exchange unavailable (%s); using torch.distributed" % e, file=sys.stderr)
+            # Bring the communicator up on a watchdog: ncclCommInitRank between devices cannot be
+            # rehearsed on the one-GPU development box, and a hang there must not take the whole run
+            # with it.  All ranks then agree (a torch.distributed reduction) on which path to use.
+            import threading
+            box = {}
+
+            def bring_up():
+                try:
+                    torch.cuda.set_device(cx.local)           # the HIP device is per thread
+                    from gcmiipy_amd.rccl import RcclP2P
+                    ring = RcclP2P(dist, cx.rank, cx.world)
+                    ring.self_check()
+                    box["ring"] = ring
+                except Exception as e:      # noqa: BLE001 -- any failure: the torch path still works
+                    box["err"] = e
+
+            th = threading.Thread(target=bring_up, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("GCM_BENCH_RCCL_TIMEOUT_S", "120")))
+            ok = torch.tensor([1 if "ring" in box else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                cx.ring, cx.exchange = box["ring"], "RCCL ncclSend/ncclRecv groups (gcmiipy_amd.rccl)"
+            else:
+                cx.stuck = th.is_alive()
+                print("bench.py: direct RCCL exchange unavailable on some rank (%s); using torch.distributed"
+                      % box.get("err", "timed out" if th.is_alive() else "peer failed"), file=sys.stderr)
 
     main_res = run_workload(cx, a.workload, a.steps, a.warmup, a.variant)
     also = {}
@@ -409,9 +429,12 @@ def main():
             out["also"] = also
     if cx.dist is not None:
         cx.dist.barrier()
-        cx.dist.destroy_process_group()
     if cx.rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if cx.stuck:            # a bring-up thread still sits in RCCL: do not wait for it at interpreter exit
+        os._exit(0)
+    if cx.dist is not None:
+        cx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":
