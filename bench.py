@@ -283,6 +283,8 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
                 traffic = tj[name][("gcm::" + kname.split(" ")[0])]["hbm_bytes_per_launch"]   # fp64 runs only
+                if "two steps per launch" in kname:
+                    traffic /= 2.0                          # per step, as kernel_ms
             except Exception:
                 pass
             # context: what a plain device-to-device copy of the same bytes (state in, state out)
