@@ -19,6 +19,8 @@ VARIANT_AUTO, VARIANT_STAGED, VARIANT_FUSED = 0, 1, 2
 F64, F32 = 0, 1
 ADV_UPWIND, ADV_FV_UPWIND, ADV_FV_PLAIN, ADV_VANLEER, ADV_MOMENTUM = range(5)
 DIAG_ANY_NAN, DIAG_MAX_U, DIAG_MEAN_P, DIAG_SUM_P, DIAG_MIN_U, DIAG_MAX_V, DIAG_MIN_V = range(7)
+DIAG_TV_P, DIAG_TV_U, DIAG_TV_V, DIAG_TV_T, DIAG_TV_Q = range(7, 12)
+FL_VAN_LEER, FL_CALC_R, FL_DONOR_FLUX, FL_DONOR_ADVECTION = range(4)
 OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 
 _dp = C.POINTER(C.c_double)
@@ -55,6 +57,8 @@ SYMBOLS = {
     "gcm_set_star": (C.c_int, [_H] + [C.c_void_p] * 5),
     "gcm_diag": (C.c_int, [_H, C.c_int, _dp]),
     "gcm_energy": (C.c_int, [_H, _dp, C.c_int, _dp]),
+    "gcm_stats": (C.c_int, [_H, _dp, C.c_int, _dp]),
+    "gcm_flux_limiter": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
     "gcm_set_ground": (C.c_int, [_H, C.c_void_p]),
     "gcm_get_ground": (C.c_int, [_H, C.c_void_p]),
     "gcm_grey_radiation": (C.c_int, [_H] + [C.c_double] * 4 + [_dp, _dp, C.c_void_p, C.c_void_p]),

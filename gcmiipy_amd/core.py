@@ -58,6 +58,7 @@ class Core:
         cfg.tracer, cfg.variant, cfg.filter = tracer, variant, 1 if filter else 0
         cfg.nranks, cfg.rank = nranks, rank
         cfg.global_height = self.H if global_height is None else int(global_height)
+        self.global_height = cfg.global_height
         cfg.row0 = row0
         cfg.device = device
         cfg.halo_steps = halo_steps
@@ -164,6 +165,20 @@ class Core:
         _check(lib.gcm_energy(self._h, _tab(a), a.size, out), self._h)
         return tuple(out)
 
+    def stats(self, area):
+        """the STATS record of full_timestep (no_limits_2_5d.py:85-91) by one launch and one
+        synchronisation -> dict(u_max, u_min, v_max, v_min, ke=(ke, ate, geo, total), nans)"""
+        a = as_f64(np.asarray(area, dtype=np.float64).reshape(-1), name="area")
+        out = (C.c_double * 9)()
+        _check(lib.gcm_stats(self._h, _tab(a), a.size, out), self._h)
+        return {"u_max": out[0], "u_min": out[1], "v_max": out[2], "v_min": out[3],
+                "ke": (out[4], out[5], out[6], out[7]), "nans": out[8]}
+
+    def total_variation(self, field):
+        """constants.get_total_variation of one field of the resident state (constants.py:105-108):
+        sum |q - roll(q, -1, 0)| over axis 0 of the reference layout, by a device reduction"""
+        return self.diag(_lib.DIAG_TV_P + int(field))
+
     # -- column physics (GCM_PE25D) ----------------------------------------------------
     def set_ground(self, gt):
         _check(lib.gcm_set_ground(self._h, _ptr(as_f64(gt, (self.H, self.W), "gt"))), self._h)
@@ -174,7 +189,7 @@ class Core:
         return out
 
     def _latlon(self, geom):
-        lat = as_f64(np.asarray(geom.lat, dtype=np.float64).reshape(-1), name="lat")
+        lat = as_f64(np.asarray(geom.lat, dtype=np.float64).reshape(-1), (self.global_height,), "lat")
         lon = as_f64(np.asarray(geom.long, dtype=np.float64).reshape(-1), (self.W,), "long")
         return lat, lon
 

@@ -50,6 +50,7 @@ struct gcm_handle {
     // per-launch timing of the dominant kernel (gcm_time_steps second pass)
     bool timing = false;
     std::vector<hipEvent_t> ev;
+    std::vector<hipEvent_t> region_ev;   // gcm_time_steps: start / end of the timed region
     size_t ev_used = 0;
 
     Pe25d *pe = nullptr;  // GCM_PE25D state (pe25d_kernels.h)
@@ -116,6 +117,7 @@ int gcm_destroy(gcm_handle *h) {
     if (h->pe) pe25d_destroy(h->pe);
     for (void *p : h->allocs) (void)hipFree(p);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->region_ev) (void)hipEventDestroy(e);
     delete h;
     return GCM_OK;
 }
@@ -257,7 +259,7 @@ static int xfer(gcm_handle *h, double *const dev[GCM_NFIELDS], const double *con
 int gcm_set_state(gcm_handle *h, const double *p, const double *u, const double *v,
                   const double *t, const double *q) {
     if (!h) return GCM_ERR_ARG;
-    if (h->pe) return pe25d_set(h->pe, false, p, u, v, t, q, &h->err);
+    if (h->pe) return pe25d_set(h->pe, false, p, u, v, t, q, h->stream, &h->err);
     const double *src[GCM_NFIELDS] = {p, u, v, t, q};
     h->star_valid = false;
     return xfer(h, h->cur, src, nullptr, true);
@@ -265,7 +267,7 @@ int gcm_set_state(gcm_handle *h, const double *p, const double *u, const double 
 
 int gcm_get_state(gcm_handle *h, double *p, double *u, double *v, double *t, double *q) {
     if (!h) return GCM_ERR_ARG;
-    if (h->pe) return pe25d_get(h->pe, false, p, u, v, t, q, &h->err);
+    if (h->pe) return pe25d_get(h->pe, false, p, u, v, t, q, h->stream, &h->err);
     double *dst[GCM_NFIELDS] = {p, u, v, t, q};
     return xfer(h, h->cur, nullptr, dst, false);
 }
@@ -273,7 +275,7 @@ int gcm_get_state(gcm_handle *h, double *p, double *u, double *v, double *t, dou
 int gcm_set_star(gcm_handle *h, const double *p, const double *u, const double *v,
                  const double *t, const double *q) {
     if (!h) return GCM_ERR_ARG;
-    if (h->pe) return pe25d_set(h->pe, true, p, u, v, t, q, &h->err);
+    if (h->pe) return pe25d_set(h->pe, true, p, u, v, t, q, h->stream, &h->err);
     if (q && h->cfg.model != GCM_PE2D)
         return fail(h, GCM_ERR_ARG, "set_star: the tracer has no predicted state");
     if (h->cfg.model == GCM_PE2D) {
@@ -290,7 +292,7 @@ int gcm_set_star(gcm_handle *h, const double *p, const double *u, const double *
 
 int gcm_get_star(gcm_handle *h, double *p, double *u, double *v, double *t, double *q) {
     if (!h) return GCM_ERR_ARG;
-    if (h->pe) return pe25d_get(h->pe, true, p, u, v, t, q, &h->err);
+    if (h->pe) return pe25d_get(h->pe, true, p, u, v, t, q, h->stream, &h->err);
     if (!h->star_valid) return fail(h, GCM_ERR_STATE, "get_star: no predicted state yet");
     if (h->cfg.model == GCM_PE2D) {
         double *dst5[GCM_NFIELDS] = {p, u, v, t, q};
@@ -501,7 +503,7 @@ int gcm_comm_stream(gcm_handle *h, void **stream) {
 int gcm_set_halo_buffers(gcm_handle *h, void *north_send, void *south_send) {
     if (!h) return GCM_ERR_ARG;
     if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_set_halo_buffers: GCM_PE25D latitude bands only");
-    return pe25d_set_halo_buffers(h->pe, north_send, south_send, &h->err);
+    return pe25d_set_halo_buffers(h->pe, north_send, south_send, h->stream, &h->err);
 }
 
 int gcm_wait_edges(gcm_handle *h, void *stream) {
@@ -676,6 +678,38 @@ __global__ __launch_bounds__(256) void diag_kernel(const T *x, long n, double *o
     }
 }
 
+// get_total_variation (constants.py:105-108): sum |x - roll(x, -1, axis)| for an array viewed as
+// [n_outer][n_axis][n_inner]; wrap == 0: the slab after the last one (a band's south ghost row) is
+// differenced instead of slab 0.  out[4*b + 2] = the block's partial sum, [3] = its NaN count.
+template <typename T>
+__global__ __launch_bounds__(256) void tv_kernel(const T *x, long n_outer, long n_axis, long n_inner, int wrap, double *out) {
+    const long n = n_outer * n_axis * n_inner;
+    double sm = 0.0, nn = 0.0;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const long i = e % n_inner, r = e / n_inner;
+        const long a = r % n_axis, o = r / n_axis;
+        const long an = (a + 1 == n_axis && wrap) ? 0 : a + 1;
+        const double v = (double)x[e], w = (double)x[(o * n_axis + an) * n_inner + i];
+        const double d = fabs(v - w);
+        if (d != d) nn += 1.0;
+        sm += d;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sm += __shfl_down(sm, o);
+        nn += __shfl_down(nn, o);
+    }
+    __shared__ double s[4][2];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s[w][0] = sm; s[w][1] = nn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[4 * blockIdx.x] = 0.0;
+        out[4 * blockIdx.x + 1] = 0.0;
+        out[4 * blockIdx.x + 2] = s[0][0] + s[1][0] + s[2][0] + s[3][0];
+        out[4 * blockIdx.x + 3] = s[0][1] + s[1][1] + s[2][1] + s[3][1];
+    }
+}
+
 extern "C" {
 
 int gcm_diag(gcm_handle *h, int kind, double *out) {
@@ -683,7 +717,12 @@ int gcm_diag(gcm_handle *h, int kind, double *out) {
     const double *x = nullptr;
     long n = (long)h->H * h->W;
     int f;
+    const bool tv = kind >= GCM_DIAG_TV_P && kind <= GCM_DIAG_TV_Q;
     switch (kind) {
+        case GCM_DIAG_TV_P: case GCM_DIAG_TV_U: case GCM_DIAG_TV_V: case GCM_DIAG_TV_T: case GCM_DIAG_TV_Q:
+            f = kind - GCM_DIAG_TV_P;
+            if (!h->pe && !h->has[f]) return fail(h, GCM_ERR_ARG, "gcm_diag: the model has no such field");
+            break;
         case GCM_DIAG_ANY_NAN: case GCM_DIAG_MAX_U: case GCM_DIAG_MIN_U: f = GCM_U; break;
         case GCM_DIAG_MEAN_P: case GCM_DIAG_SUM_P: f = GCM_P; break;
         case GCM_DIAG_MAX_V: case GCM_DIAG_MIN_V: f = GCM_V; break;
@@ -697,7 +736,17 @@ int gcm_diag(gcm_handle *h, int kind, double *out) {
         x = h->cur[f];
     }
     const int nb = gcm_handle::kDiagBlocks;
-    if (f32)
+    if (tv) {
+        long n_outer = 1, n_axis = h->H, n_inner = h->W;
+        int wrap = h->wrap ? 1 : 0;
+        if (h->pe) pe25d_tv_shape(h->pe, f, &n_outer, &n_axis, &n_inner, &wrap);
+        if (f32)
+            hipLaunchKernelGGL(tv_kernel<float>, dim3(nb), dim3(256), 0, h->stream, (const float *)xv, n_outer, n_axis,
+                               n_inner, wrap, h->diag_dev);
+        else
+            hipLaunchKernelGGL(tv_kernel<double>, dim3(nb), dim3(256), 0, h->stream, h->pe ? (const double *)xv : x,
+                               n_outer, n_axis, n_inner, wrap, h->diag_dev);
+    } else if (f32)
         hipLaunchKernelGGL(diag_kernel<float>, dim3(nb), dim3(256), 0, h->stream, (const float *)xv, n, h->diag_dev);
     else
         hipLaunchKernelGGL(diag_kernel<double>, dim3(nb), dim3(256), 0, h->stream,
@@ -719,6 +768,7 @@ int gcm_diag(gcm_handle *h, int kind, double *out) {
         case GCM_DIAG_MIN_U: case GCM_DIAG_MIN_V: *out = nn > 0 ? NAN : mn; break;
         case GCM_DIAG_MEAN_P: *out = sm / (double)n; break;
         case GCM_DIAG_SUM_P: *out = sm; break;
+        default: *out = nn > 0 ? NAN : sm; break;          // total variation
     }
     return GCM_OK;
 }
@@ -726,20 +776,28 @@ int gcm_diag(gcm_handle *h, int kind, double *out) {
 int gcm_energy(gcm_handle *h, const double *area, int area_len, double *out4) {
     if (!h || !area || !out4 || area_len < 1) return GCM_ERR_ARG;
     if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_energy: GCM_PE25D only");
-    int rc = pe25d_energy(h->pe, area, area_len, out4, &h->err);
+    double o9[9];
+    int rc = pe25d_stats(h->pe, area, area_len, o9, h->stream, &h->err);
+    if (rc == GCM_OK) for (int q = 0; q < 4; ++q) out4[q] = o9[4 + q];
     return rc;
+}
+
+int gcm_stats(gcm_handle *h, const double *area, int area_len, double *out9) {
+    if (!h || !area || !out9 || area_len < 1) return GCM_ERR_ARG;
+    if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_stats: GCM_PE25D only");
+    return pe25d_stats(h->pe, area, area_len, out9, h->stream, &h->err);
 }
 
 int gcm_set_ground(gcm_handle *h, const double *gt) {
     if (!h || !gt) return GCM_ERR_ARG;
     if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_set_ground: GCM_PE25D only");
-    return pe25d_ground(h->pe, true, gt, nullptr, &h->err);
+    return pe25d_ground(h->pe, true, gt, nullptr, h->stream, &h->err);
 }
 
 int gcm_get_ground(gcm_handle *h, double *gt) {
     if (!h || !gt) return GCM_ERR_ARG;
     if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_get_ground: GCM_PE25D only");
-    return pe25d_ground(h->pe, false, nullptr, gt, &h->err);
+    return pe25d_ground(h->pe, false, nullptr, gt, h->stream, &h->err);
 }
 
 int gcm_grey_radiation(gcm_handle *h, double utc, double t_lw, double t_sw, double albedo,
@@ -760,9 +818,15 @@ int gcm_solar_step(gcm_handle *h, double dt, double utc, double t_lw, double t_s
 
 int gcm_time_steps(gcm_handle *h, int nsteps, double dt, double *ms, double *kernel_ms_avg) {
     if (!h || nsteps < 1 || !ms) return GCM_ERR_ARG;
-    hipEvent_t e0, e1;
-    HIPCHK(h, hipEventCreate(&e0));
-    HIPCHK(h, hipEventCreate(&e1));
+    // the two region events are created once and kept in the handle (freed by gcm_destroy), so no
+    // exit of this function leaks them.  NOTE: with kernel_ms_avg != NULL the state advances
+    // 2 * nsteps steps (the per-launch pass re-runs the same number of steps).
+    while (h->region_ev.size() < 2) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreate(&e));
+        h->region_ev.push_back(e);
+    }
+    const hipEvent_t e0 = h->region_ev[0], e1 = h->region_ev[1];
     HIPCHK(h, hipEventRecord(e0, h->stream));
     int rc = gcm_step(h, nsteps, dt);
     if (rc) return rc;
@@ -771,8 +835,6 @@ int gcm_time_steps(gcm_handle *h, int nsteps, double dt, double *ms, double *ker
     float t = 0;
     HIPCHK(h, hipEventElapsedTime(&t, e0, e1));
     *ms = t;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     if (kernel_ms_avg) {
         // second pass: one event pair around every launch of the dominant kernel
         const size_t need = 2 * (size_t)nsteps;

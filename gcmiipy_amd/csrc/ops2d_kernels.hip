@@ -122,6 +122,31 @@ struct DevBuf {
         return (double *)d;
     }
 };
+// flux_limiter.py:10-32 on a periodic 1-D array; one thread per cell.  IEEE division and no
+// contraction: the results (and so the b != 0 / u > 0 masks they carry) are NumPy's bit for bit.
+__global__ __launch_bounds__(256) void flux_limiter_kernel(int kind, int n, const double *q, const double *u,
+                                                           double dx, double dt, double *out) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int im = i == 0 ? n - 1 : i - 1, ip = i + 1 == n ? 0 : i + 1;
+    if (kind == GCM_FL_VAN_LEER) {
+        const double r = q[i], ar = fabs(r);
+        out[i] = __ddiv_rn(r + ar, 1.0 + ar);                                  // :10-11
+    } else if (kind == GCM_FL_CALC_R) {
+        const double a = q[i] - q[im], b = q[ip] - q[i];
+        out[i] = b != 0.0 ? __ddiv_rn(a, b) : 0.0;                             // :17-19, where=(b != 0)
+    } else {
+        const double f = (u[i] > 0.0 ? q[i] : q[ip]) * u[i];                    // :24-25, strict u > 0
+        if (kind == GCM_FL_DONOR_FLUX) {
+            out[i] = f;
+        } else {
+            const double fm = (u[im] > 0.0 ? q[im] : q[i]) * u[im];
+            out[i] = q[i] + __ddiv_rn((fm - f) * dt, dx);                       // :32
+        }
+    }
+}
+
 thread_local std::string g_ops_error;
 int ops_fail(int code, const char *m) { g_ops_error = m; return code; }
 }  // namespace
@@ -167,6 +192,21 @@ int gcm_advect2d(int scheme, int axes, int finite, int width, int height, int ns
     }
     if (hipMemcpy(q_out, qa, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
         return ops_fail(GCM_ERR_HIP, "gcm_advect2d: kernel or copy-back failed");
+    return GCM_OK;
+}
+
+int gcm_flux_limiter(int kind, int n, const double *q, const double *u, double dx, double dt, double *out) {
+    if (!q || !out || n < 1 || kind < GCM_FL_VAN_LEER || kind > GCM_FL_DONOR_ADVECTION)
+        return ops_fail(GCM_ERR_ARG, "gcm_flux_limiter: bad argument");
+    if (kind >= GCM_FL_DONOR_FLUX && !u) return ops_fail(GCM_ERR_ARG, "gcm_flux_limiter: u is required");
+    if (kind == GCM_FL_DONOR_ADVECTION && !(dx != 0.0)) return ops_fail(GCM_ERR_ARG, "gcm_flux_limiter: dx == 0");
+    if (gcm_device_count() < 1) return ops_fail(GCM_ERR_NODEVICE, "gcm_flux_limiter: no HIP device; no CPU fallback");
+    DevBuf mem;
+    double *dq = mem.get(n, q), *du = u ? mem.get(n, u) : nullptr, *o = mem.get(n);
+    if (!dq || (u && !du) || !o) return ops_fail(GCM_ERR_HIP, "gcm_flux_limiter: device allocation/upload failed");
+    hipLaunchKernelGGL(flux_limiter_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, kind, n, dq, du, dx, dt, o);
+    if (hipMemcpy(out, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return ops_fail(GCM_ERR_HIP, "gcm_flux_limiter: kernel or copy-back failed");
     return GCM_OK;
 }
 

@@ -16,13 +16,13 @@ struct SegCopy;   // sw2d_kernels.h
 Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t s, std::string *err);
 void pe25d_destroy(Pe25d *m);
 int pe25d_set(Pe25d *m, bool star, const double *p, const double *u, const double *v,
-              const double *t, const double *q, std::string *err);
+              const double *t, const double *q, hipStream_t s, std::string *err);
 int pe25d_get(Pe25d *m, bool star, double *p, double *u, double *v, double *t, double *q,
-              std::string *err);
+              hipStream_t s, std::string *err);
 int pe25d_step(Pe25d *m, double dt, hipStream_t s, std::string *err);
 int pe25d_step_part(Pe25d *m, int part, double dt, hipStream_t s, std::string *err);
 int pe25d_step_phase(Pe25d *m, int phase, double dt, hipStream_t s, std::string *err);
-int pe25d_set_halo_buffers(Pe25d *m, void *north, void *south, std::string *err);
+int pe25d_set_halo_buffers(Pe25d *m, void *north, void *south, hipStream_t s, std::string *err);
 int pe25d_wait_edges(Pe25d *m, hipStream_t s, std::string *err);
 hipStream_t pe25d_aux_stream(const Pe25d *m);
 // a new non-blocking stream that demonstrably runs beside `main` (and `other`, may be null)
@@ -30,11 +30,12 @@ hipStream_t concurrent_stream(hipStream_t main, hipStream_t other);
 int pe25d_half(Pe25d *m, int stage, double dt, hipStream_t s, std::string *err);
 size_t pe25d_halo_bytes(const Pe25d *m);
 int pe25d_halo_segments(Pe25d *m, bool pack, int side, void *dev_buf, SegCopy *c, std::string *err);
-int pe25d_ground(Pe25d *m, bool set, const double *in, double *out, std::string *err);
+int pe25d_ground(Pe25d *m, bool set, const double *in, double *out, hipStream_t s, std::string *err);
 int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, double t_sw, double albedo,
                     const double *lat, const double *lon, double *dTdt_host, double *dtg_host,
                     hipStream_t s, std::string *err);
-int pe25d_energy(Pe25d *m, const double *area_host, int area_len, double out[4], std::string *err);
+int pe25d_stats(Pe25d *m, const double *area_host, int area_len, double out[9], hipStream_t s, std::string *err);
+void pe25d_tv_shape(const Pe25d *m, int field, long *n_outer, long *n_axis, long *n_inner, int *wrap);
 const void *pe25d_field(Pe25d *m, int field, long *n, int *f32);
 void pe25d_timing(Pe25d *m, std::vector<hipEvent_t> *ev, size_t *used);
 

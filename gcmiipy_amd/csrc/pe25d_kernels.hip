@@ -30,6 +30,7 @@
 namespace gcm {
 
 constexpr int kMaxSeg = 4;      // level segments of the update kernel (short bands)
+constexpr int kMaxEdgeCols = 96; // K3: columns that are multiples of 64 (W <= 5120 + rounding)
 // real-type specific pieces: reciprocal and (p/P0)**kappa (fp32: v_rcp_f32 is 1 ulp; powf)
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float exner(float p, const double *) { return __powf(p * 1e-5f, (float)kKappa); }
@@ -42,7 +43,7 @@ struct PeArgsT {
     const T *sp, *su, *sv, *st, *sq;
     T *op, *ou, *ov, *ot, *oq;
     // intermediates
-    T *spu, *phi, *rho, *pgfu;        // 3-D
+    T *spu, *phi, *pgfu;              // 3-D (phi: even levels only, see rho_of / phi_up)
     T *pit, *pn;                      // 2-D
     T *part;                          // [nseg-1] 2-D slabs: conv summed from the top down to a segment boundary
     // tables (device)
@@ -136,6 +137,41 @@ __device__ __forceinline__ T conv_acc(T acc, T fx_hi, T fx_lo, T inv_dx, T sv_hi
 template <typename T>
 __device__ __forceinline__ T sd_of(T rc, T pit, T sgb) { return fma(-pit, sgb, rc); }
 
+// Density and geopotential are NOT kept in HBM level by level.  pe_geopot_kernel stores phi on
+// the even levels only (the anchors); the filter kernel K3 and the update kernel K4 rebuild rho on
+// every level and phi on the odd levels from the stage theta they read anyway, through the two
+// helpers below.  Contraction is off inside them, so that the three kernels round identically:
+// phi is then one well-defined field, whichever kernel evaluates it and however K4's level march
+// is segmented.
+//   rho = tp / (Rd tt), tt = t (tp/P0)**kappa                       dynamics.py:122-126
+//   phi[k] = phi[k-1] + Cp kph(t)[k-1] (pk[k-1] - pk[k])            dynamics.py:128-134 (cumsum)
+template <typename T>
+__device__ __forceinline__ T rho_of(T tp, T t, T ex) {
+#pragma clang fp contract(off)
+    const T tt = t * ex;
+    return tp * rcp(T(kRd) * tt);
+}
+template <typename T>
+__device__ __forceinline__ T stp_of(T t_lo, T t_hi, T ex_lo, T ex_hi) {
+#pragma clang fp contract(off)
+    return T(kCp) * ((t_lo + t_hi) * T(0.5)) * (ex_lo - ex_hi);
+}
+template <typename T>
+__device__ __forceinline__ T add_rn(T a, T b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+template <typename T>
+__device__ __forceinline__ T phi_up(T phi_lo, T t_lo, T t_hi, T ex_lo, T ex_hi) {
+#pragma clang fp contract(off)
+    const T stp = stp_of(t_lo, t_hi, ex_lo, ex_hi);
+    return phi_lo + stp;
+}
+// value of the wave's lane+1 (column i+1), fp32 flavour of gcm_math.h's from_east
+__device__ __forceinline__ float from_east(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
+}
+
 // ---------------------------------------------------------------- K2: column kernels
 // K2a pe_geopot_kernel: rho, phi from the stage theta and surface pressure (compute_geopotential);
 // K2b pe_pit_kernel: pit = sum_k conv and p_n from the filtered mass flux (aflux).  They are two
@@ -184,21 +220,18 @@ __global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
 #pragma unroll(LMAX > 0 ? LMAX : 6)
     for (int k = 0; k < (LMAX > 0 ? LMAX : L); ++k) {
         if (LMAX > 0 && k >= L) break;
-        const long o = c3 + (long)k * W + i;
         const T tp = spc * a.sig[k] + a.ptop;
         T t_n, ex_n;
         if (k + 1 < L) {
-            t_n = LMAX > 0 ? tcol[k + 1 < LMAX ? k + 1 : 0] : a.st[o + W];
+            t_n = LMAX > 0 ? tcol[k + 1 < LMAX ? k + 1 : 0] : a.st[c3 + (long)(k + 1) * W + i];
             ex_n = exner(spc * a.sig[k + 1] + a.ptop, tab);
         } else {
             t_n = t0;            // kp() wraps to the bottom layer, coordinates_3d.py:55-56
             ex_n = ex0;
         }
-        const T tt = t_k * ex_k;                        // t / (P0/tp)**kappa
-        const T rho = tp * rcp(T(kRd) * tt);
-        a.rho[o] = rho;
+        const T rho = rho_of(tp, t_k, ex_k);            // tp / (Rd t / (P0/tp)**kappa)
         const T s1 = (a.sig[k] * spc * rcp(rho)) * a.dsig[k];
-        const T stp = T(kCp) * ((t_k + t_n) * T(0.5)) * (ex_k - ex_n);
+        const T stp = stp_of(t_k, t_n, ex_k, ex_n);
         const T s2 = a.sigt[k] * stp;
         acc += s1 - s2;
         if (LMAX > 0) stp_reg[k] = stp;
@@ -211,8 +244,8 @@ __global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
 #pragma unroll(LMAX > 0 ? LMAX : 1)
     for (int k = 1; k < (LMAX > 0 ? LMAX : L); ++k) {        // phi = cumsum(stp_n), stp_n = km(stp)
         if (LMAX > 0 && k >= L) break;
-        run += LMAX > 0 ? stp_reg[k - 1] : pk[(k - 1) * kColThreads];
-        a.phi[c3 + (long)k * W + i] = run;
+        run = add_rn(run, LMAX > 0 ? stp_reg[k - 1] : pk[(k - 1) * kColThreads]);
+        if ((k & 1) == 0) a.phi[c3 + (long)k * W + i] = run;     // anchors: even levels only
     }
 }
 
@@ -267,11 +300,22 @@ __global__ __launch_bounds__(256) void pe_pit_kernel(PeArgsT<T> a) {
 }
 
 // ---------------------------------------------------------------- K3: pgfu = filter(pgu + phiu)
+// The workgroup of (row, level pair k0 = 2 b, k1 = k0 + 1) rebuilds rho on both levels and phi on
+// the odd one from theta (see rho_of / phi_up); phi[k0] is the anchor pe_geopot_kernel stored.
+// Column i + 1 comes from the next lane (DPP); where the next column belongs to another wave
+// (lane 63, and the row's last column, which wraps to 0) it comes from a small LDS table of the
+// columns that are multiples of 64, filled before the main loop.
+template <typename T>
+struct PgfCol { T rho0, rho1, phi0, phi1; };
+
 template <typename T, int MAXR, unsigned MASK = 0>
 __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
     using V = typename Vec2<T>::type;
     extern __shared__ unsigned char lds_raw[];
+    __shared__ double tab[kExnerTabDoubles];
+    __shared__ PgfCol<T> edge[kMaxEdgeCols];
     V *x = (V *)lds_raw;
+    for (int n = threadIdx.x; n < kExnerTabDoubles; n += blockDim.x) tab[n] = a.exner_tab[n];
     const Idx ix{a.W, a.H, a.L, a.wrap};
     const int j = a.j0 + blockIdx.x;
     const int k0 = 2 * blockIdx.y, k1 = k0 + 1;
@@ -281,48 +325,69 @@ __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
     const T inv_dxj = a.inv_dxj[jg];
     const T *sp = a.sp + ix.r2(j);
     const long o0 = ix.r3(j) + (long)k0 * W;
-    const T *phi0 = a.phi + o0, *rho0 = a.rho + o0;
-    const T sg0 = a.sig[k0], sg1 = two ? a.sig[k1] : T(0.0);
+    const T *phi0 = a.phi + o0;
+    const T *st0 = a.st + o0, *st1 = st0 + (two ? W : 0);
+    const T sg0 = a.sig[k0], sg1 = two ? a.sig[k1] : sg0;
+    const T ptop = a.ptop;
     T *out = a.pgfu + o0;
-    const auto load = [=](int i) {
+    __syncthreads();
+    const auto column = [=](int i) {
+        const T pc = sp[i];
+        const T tp0 = pc * sg0 + ptop, tp1 = pc * sg1 + ptop;
+        const T ex0 = exner(tp0, tab), ex1 = exner(tp1, tab);
+        const T t0 = st0[i], t1 = st1[i];
+        PgfCol<T> c;
+        c.rho0 = rho_of(tp0, t0, ex0);
+        c.rho1 = rho_of(tp1, t1, ex1);
+        c.phi0 = phi0[i];
+        c.phi1 = phi_up(c.phi0, t0, t1, ex0, ex1);
+        return c;
+    };
+    for (int e = threadIdx.x; e * 64 < W; e += blockDim.x) edge[e] = column(e * 64);
+    __syncthreads();
+    // every lane of a wave goes through the loop body (DPP reads its neighbour lane): columns past
+    // the end are clamped and not stored
+    const int lane = threadIdx.x & 63;
+    const auto value = [&](int i_raw) {
+        const int i = i_raw < W ? i_raw : W - 1;
         const int ie = i + 1 == W ? 0 : i + 1;
+        const PgfCol<T> c = column(i);
+        PgfCol<T> e;
+        e.rho0 = from_east(c.rho0); e.rho1 = from_east(c.rho1);
+        e.phi0 = from_east(c.phi0); e.phi1 = from_east(c.phi1);
+        if (lane == 63 || ie == 0) e = edge[ie >> 6];
         const T pc = sp[i], pe = sp[ie];
         const T iphp = (pc + pe) * T(0.5);
         const T gradp = (pe - pc) * inv_dxj;
-        T v[2] = {T(0.0), T(0.0)};
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (s == 1 && !two) break;
-            const T *phi = phi0 + s * W, *rho = rho0 + s * W;
-            const T sg = s ? sg1 : sg0;
-            const T phiu = iphp * ((phi[ie] - phi[i]) * inv_dxj);                   // dynamics.py:159
-            const T ppih = (sg * pc + sg * pe) * T(0.5);
-            const T rhou = (rho[i] + rho[ie]) * T(0.5);
-            const T pgu = ppih * rcp(rhou) * gradp;                                 // dynamics.py:162-165
-            v[s] = pgu + phiu;
-        }
-        return mkv<V>(v[0], v[1]);
+        const T phiu0 = iphp * ((e.phi0 - c.phi0) * inv_dxj);                      // dynamics.py:159
+        const T pgu0 = ((sg0 * pc + sg0 * pe) * T(0.5)) * rcp((c.rho0 + e.rho0) * T(0.5)) * gradp;   // dynamics.py:162-165
+        const T phiu1 = iphp * ((e.phi1 - c.phi1) * inv_dxj);
+        const T pgu1 = ((sg1 * pc + sg1 * pe) * T(0.5)) * rcp((c.rho1 + e.rho1) * T(0.5)) * gradp;
+        return mkv<V>(pgu0 + phiu0, two ? pgu1 + phiu1 : T(0.0));
     };
     const auto store = [=](int i, V v) {
         out[i] = v.x;
         if (two) out[W + i] = v.y;
     };
+    const int wpad = (W + 63) / 64 * 64;
     if (a.filter && W > 1) {
+        for (int i = threadIdx.x; i < wpad; i += blockDim.x) {
+            const V v = value(i);
+            if (i < W) x[i] = v;
+        }
+        __syncthreads();
         if (MAXR > 0) {
-            // the row goes through LDS first: the first pass would otherwise hold the ~10 loads of
-            // each of its R elements in flight at once (165 VGPRs; 122 this way: 4 waves/SIMD)
-            for (int i = threadIdx.x; i < W; i += blockDim.x) x[i] = load(i);
-            __syncthreads();
             const auto from_x = [x](int i) { return x[i]; };
             filter_rows_composite<MAXR, MASK, T>(x, from_x, store, a.tw, a.cplan, W, a.smul + (long)jg * (W / 2 + 1), true);
         } else {
-            for (int i = threadIdx.x; i < W; i += blockDim.x) x[i] = load(i);
-            __syncthreads();
             const V *res = filter_rows<T>(x, x + W, a.tw, a.plan, a.smul + (long)jg * (W / 2 + 1));
             for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, res[i]);
         }
     } else {
-        for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, load(i));
+        for (int i = threadIdx.x; i < wpad; i += blockDim.x) {
+            const V v = value(i);
+            if (i < W) store(i, v);
+        }
     }
 }
 
@@ -335,6 +400,9 @@ __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
 constexpr int kUpdThreads = 64;   // one wave per workgroup: packs the rounds of a short band best (256: +2.5 %)
 template <typename T>
 __global__ __launch_bounds__(kUpdThreads) void pe_update_kernel(PeArgsT<T> a) {
+    __shared__ double tab[kExnerTabDoubles];
+    for (int n = threadIdx.x; n < kExnerTabDoubles; n += kUpdThreads) tab[n] = a.exner_tab[n];
+    __syncthreads();
     const Idx ix{a.W, a.H, a.L, a.wrap};
     const int W = a.W, L = a.L;
     const int iblocks = (W + kUpdThreads - 1) / kUpdThreads;
@@ -400,6 +468,13 @@ __global__ __launch_bounds__(kUpdThreads) void pe_update_kernel(PeArgsT<T> a) {
         sd_ep = sd_of(rc_e, pit_e, sgb_hi);
         sd_sp = sd_of(rc_s, pit_s, sgb_hi);
     }
+    // rho and phi of this column and its south neighbour are rebuilt per level (rho_of / phi_up):
+    // an odd level k takes the anchor phi[k-1] that pe_geopot_kernel stored and steps up from it,
+    // and leaves the level k-1 values it needed (anchor, exner factors, the south theta) for the
+    // next, even, iteration -- two exner evaluations per level and column on average
+    const T ptop = a.ptop;
+    bool have_lo = false;
+    T lo_ex_c = T(0.0), lo_ex_s = T(0.0), lo_phi_c = T(0.0), lo_phi_s = T(0.0), lo_st_s = T(0.0);
     for (int k = k_hi - 1; k >= k_lo; --k) {
         const long kc = (long)k * W;
         T su_m, sv_m, st_m, sq_m;
@@ -451,8 +526,28 @@ __global__ __launch_bounds__(kUpdThreads) void pe_update_kernel(PeArgsT<T> a) {
         const T dvt = (pvvm - pvvp) * inv_dy + (pvum - pvup) * inv_dxh + cor_v;
         // ---- pgf v-part, dynamics.py:160,167-169 (the u-part went through K3)
         const T sg = a.sig[k];
-        const T phi_c = a.phi[rc + kc + i], phi_s = a.phi[rs + kc + i];
-        const T rho_c = a.rho[rc + kc + i], rho_s = a.rho[rs + kc + i];
+        T ex_c, ex_s, phi_c, phi_s, st_s;
+        if (have_lo) {
+            ex_c = lo_ex_c; ex_s = lo_ex_s; phi_c = lo_phi_c; phi_s = lo_phi_s; st_s = lo_st_s;
+        } else {
+            ex_c = exner(sp_c * sg + ptop, tab);
+            ex_s = exner(sp_s * sg + ptop, tab);
+            st_s = a.st[rs + kc + i];
+            phi_c = phi_s = T(0.0);
+            if ((k & 1) == 0) { phi_c = a.phi[rc + kc + i]; phi_s = a.phi[rs + kc + i]; }
+        }
+        have_lo = (k & 1) != 0;
+        if (have_lo) {                                            // k odd: k - 1 >= 0 is an anchor level
+            const T sg_lo = a.sig[k - 1];
+            lo_ex_c = exner(sp_c * sg_lo + ptop, tab);
+            lo_ex_s = exner(sp_s * sg_lo + ptop, tab);
+            lo_st_s = a.st[rs + kc - W + i];
+            lo_phi_c = a.phi[rc + kc - W + i];
+            lo_phi_s = a.phi[rs + kc - W + i];
+            phi_c = phi_up(lo_phi_c, st_m, st_c, lo_ex_c, ex_c);
+            phi_s = phi_up(lo_phi_s, lo_st_s, st_s, lo_ex_s, ex_s);
+        }
+        const T rho_c = rho_of(sp_c * sg + ptop, st_c, ex_c), rho_s = rho_of(sp_s * sg + ptop, st_s, ex_s);
         const T phiv = jph_c * ((phi_s - phi_c) * inv_dy);
         const T pgv = ((sg * sp_c + sg * sp_s) * T(0.5)) * rcp((rho_c + rho_s) * T(0.5)) * ((sp_s - sp_c) * inv_dy);
         // ---- vertical advection, dynamics.py:49-52 with iph(sd), jph(sd), sd
@@ -475,7 +570,7 @@ __global__ __launch_bounds__(kUpdThreads) void pe_update_kernel(PeArgsT<T> a) {
         if (pole_edge) v_n *= T(0.0);                               // v_n[:, -1, :] *= 0, dynamics.py:222
         // ---- advec_t for t and q, dynamics.py:174-181,214-219
         const T st_e = a.st[rc + kc + ie], st_w = a.st[rc + kc + iw];
-        const T st_s = a.st[rs + kc + i], st_n = a.st[rn + kc + i];
+        const T st_n = a.st[rn + kc + i];
         const T sq_e = a.sq[rc + kc + ie], sq_w = a.sq[rc + kc + iw];
         const T sq_s = a.sq[rs + kc + i], sq_n = a.sq[rn + kc + i];
         const T adt = (spu_c * ((st_c + st_e) * T(0.5)) - spu_w * ((st_w + st_c) * T(0.5))) * inv_dxj +
@@ -498,12 +593,14 @@ __global__ __launch_bounds__(kUpdThreads) void pe_update_kernel(PeArgsT<T> a) {
 
 using PeArgs = PeArgsT<double>;   // the diagnostics and the column physics below are fp64 only
 
-// ---------------------------------------------------------------- calc_energy (no_limits_2_5d.py:35-60)
-// thread per (j,i) column; out[4*block + {0,1,2}] = partial sums of ke, ate, geo
+// ---------------------------------------------------------------- calc_energy + STATS (no_limits_2_5d.py:35-60,85-91)
+// thread per (j,i) column; out[kStatsWords*block + {0,1,2}] = partial sums of ke, ate, geo,
+// {3,4,5,6} = max u, min u, max v, min v of the block's columns, {7} = NaNs seen in u and v
+constexpr int kStatsWords = 8;
 __global__ __launch_bounds__(256) void pe_energy_kernel(PeArgs a, const double *area, int area_by_i,
                                                         double *out) {
     __shared__ double tab[kExnerTabDoubles];
-    __shared__ double red[3][4];
+    __shared__ double red[kStatsWords][4];
     tab[threadIdx.x] = a.exner_tab[threadIdx.x];
     __syncthreads();
     const Idx ix{a.W, a.H, a.L, a.wrap};
@@ -511,6 +608,7 @@ __global__ __launch_bounds__(256) void pe_energy_kernel(PeArgs a, const double *
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int j = blockIdx.y;
     double ke = 0.0, ate = 0.0, geo = 0.0;
+    double umax = -INFINITY, umin = INFINITY, vmax = -INFINITY, vmin = INFINITY, nn = 0.0;
     if (i < W) {
         const int iw = i == 0 ? W - 1 : i - 1;
         const double pc = a.p[ix.r2(j) + i];
@@ -519,8 +617,12 @@ __global__ __launch_bounds__(256) void pe_energy_kernel(PeArgs a, const double *
         double depth = 0.0;
         for (int k = 0; k < L; ++k) {
             const long o = c3 + (long)k * W;
-            const double uc = (a.u[o + i] + a.u[o + iw]) * 0.5;                   // imh(u)
-            const double vc = (a.v[o + i] + a.v[n3 + (long)k * W + i]) * 0.5;     // jmh(v)
+            const double u_c = a.u[o + i], v_c = a.v[o + i];
+            umax = fmax(umax, u_c); umin = fmin(umin, u_c);
+            vmax = fmax(vmax, v_c); vmin = fmin(vmin, v_c);
+            if (u_c != u_c || v_c != v_c) nn += 1.0;
+            const double uc = (u_c + a.u[o + iw]) * 0.5;                          // imh(u)
+            const double vc = (v_c + a.v[n3 + (long)k * W + i]) * 0.5;            // jmh(v)
             const double mag = sqrt(uc * uc + vc * vc);
             const double tp = pc * a.sig[k] + a.ptop;
             const double tt = a.t[o + i] * exner(tp, tab);
@@ -537,13 +639,24 @@ __global__ __launch_bounds__(256) void pe_energy_kernel(PeArgs a, const double *
         ke += __shfl_down(ke, o);
         ate += __shfl_down(ate, o);
         geo += __shfl_down(geo, o);
+        umax = fmax(umax, __shfl_down(umax, o)); umin = fmin(umin, __shfl_down(umin, o));
+        vmax = fmax(vmax, __shfl_down(vmax, o)); vmin = fmin(vmin, __shfl_down(vmin, o));
+        nn += __shfl_down(nn, o);
     }
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[0][w] = ke; red[1][w] = ate; red[2][w] = geo; }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][w] = ke; red[1][w] = ate; red[2][w] = geo;
+        red[3][w] = umax; red[4][w] = umin; red[5][w] = vmax; red[6][w] = vmin; red[7][w] = nn;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double *o = out + 4 * ((long)blockIdx.y * gridDim.x + blockIdx.x);
+        double *o = out + kStatsWords * ((long)blockIdx.y * gridDim.x + blockIdx.x);
         for (int q = 0; q < 3; ++q) o[q] = red[q][0] + red[q][1] + red[q][2] + red[q][3];
+        o[3] = fmax(fmax(red[3][0], red[3][1]), fmax(red[3][2], red[3][3]));
+        o[4] = fmin(fmin(red[4][0], red[4][1]), fmin(red[4][2], red[4][3]));
+        o[5] = fmax(fmax(red[5][0], red[5][1]), fmax(red[5][2], red[5][3]));
+        o[6] = fmin(fmin(red[6][0], red[6][1]), fmin(red[6][2], red[6][3]));
+        o[7] = red[7][0] + red[7][1] + red[7][2] + red[7][3];
     }
 }
 
@@ -648,7 +761,8 @@ struct PeBufs {
     using T2 = typename Vec2<T>::type;
     // state sets: 0/1 ping-pong (cur = set[cur_i]), 2 = star.  [f] p,u,v,t,q; interior pointers
     T *st[3][GCM_NFIELDS] = {};
-    T *spu = nullptr, *phi = nullptr, *rho = nullptr, *pgfu = nullptr, *pit = nullptr, *pn = nullptr;
+    T *spu = nullptr, *phi = nullptr, *pgfu = nullptr, *pit = nullptr, *pn = nullptr;
+    T *rad_scr = nullptr;                       // 3-D scratch of the radiation kernel, allocated on first use
     T *part = nullptr;                          // (kMaxSeg - 1) slabs like pit
     T *cor_u = nullptr, *cor_v = nullptr;
     T *inv_dxj = nullptr, *inv_dxh = nullptr, *sig = nullptr, *dsig = nullptr, *inv_dsig = nullptr,
@@ -673,9 +787,12 @@ struct Pe25d {
     FftPlan plan{};
     SuperPlan cplan{};
     double *gt = nullptr;                       // ground temperature [H][W] (column physics)
+    double *stats_dev = nullptr;                // gcm_stats: block partials, then the area table
+    std::vector<double> stats_host, area_host;
     double *rad_tab = nullptr;                  // 5 x [L] level tables of the last radiation call
     double *rad_geo = nullptr;                  // coslat[Hg], sinlat[Hg], lon[W]
     double rad_key[2] = {-1.0, -1.0};           // (t_lw, t_sw) the level tables were built for
+    std::vector<double> rad_tab_host, rad_geo_host, rad_latlon;   // host copies (upload sources, change detection)
     std::vector<hipEvent_t> *ev = nullptr;
     size_t *ev_used = nullptr;
     hipStream_t aux = nullptr;                  // second stream of a stage (K2a -> K3), see half_t
@@ -757,7 +874,7 @@ static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
             if (!dev_upload<T>(m, &d, nullptr, f == GCM_P ? n2 : n3)) return "state";
             B.st[s][f] = d + (size_t)kGhost * W * (f == GCM_P ? 1 : L);
         }
-    T **inter3[] = {&B.spu, &B.phi, &B.rho, &B.pgfu};
+    T **inter3[] = {&B.spu, &B.phi, &B.pgfu};
     for (T **pp : inter3) {
         T *d = nullptr;
         if (!dev_upload<T>(m, &d, nullptr, n3)) return "intermediate";
@@ -925,8 +1042,8 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
         return (Pe25d *)nullptr;
     };
     if (W > 1) make_super_plan(W, &m->cplan);
-    if (W > 1 && (!make_plan(W, &m->plan) || (size_t)W * 32 > 160 * 1024)) {
-        *err = "GCM_PE25D: width not supported by the in-LDS FFT (too many factors or > 5120)";
+    if (W > 1 && (!make_plan(W, &m->plan) || (size_t)W * 32 + 8192 > 160 * 1024)) {
+        *err = "GCM_PE25D: width not supported by the in-LDS FFT (too many factors or > 4864)";
         pe25d_destroy(m);
         return nullptr;
     }
@@ -980,60 +1097,58 @@ void pe25d_destroy(Pe25d *m) {
     delete m;
 }
 
+// State transfers run on the handle's stream `s` and synchronise only that stream: other handles
+// and streams of the process are not stalled.  The float64 staging buffer is reused field by field,
+// which the stream order makes safe.
 template <typename T>
 static int xfer_t(Pe25d *m, int set, bool to_dev, const double *const in[GCM_NFIELDS],
-                  double *const out[GCM_NFIELDS], std::string *err) {
+                  double *const out[GCM_NFIELDS], hipStream_t s, std::string *err) {
     PeBufs<T> &B = bufs<T>(m);
     const int W = m->W, H = m->H;
-    for (int f = 0; f < GCM_NFIELDS; ++f) {
+    hipError_t e = hipSuccess;
+    for (int f = 0; f < GCM_NFIELDS && e == hipSuccess; ++f) {
         const void *hp = to_dev ? (const void *)in[f] : (const void *)out[f];
         if (!hp) continue;
         const int L = f == GCM_P ? 1 : m->L;
         const size_t bytes = sizeof(double) * (size_t)H * W * L;
-        hipError_t e = hipSuccess;
         if (to_dev) {
-            e = hipMemcpy(m->stage3, in[f], bytes, hipMemcpyHostToDevice);
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(pe_to_device_kernel<T>, dim3(1024), dim3(256), 0, nullptr, B.st[set][f],
-                                   m->stage3, W, H, L);
-                e = hipDeviceSynchronize();
-            }
+            e = hipMemcpyAsync(m->stage3, in[f], bytes, hipMemcpyHostToDevice, s);
+            if (e == hipSuccess)
+                hipLaunchKernelGGL(pe_to_device_kernel<T>, dim3(1024), dim3(256), 0, s, B.st[set][f], m->stage3, W, H, L);
         } else {
-            hipLaunchKernelGGL(pe_to_host_kernel<T>, dim3(1024), dim3(256), 0, nullptr, m->stage3,
-                               B.st[set][f], W, H, L);
-            e = hipMemcpy(out[f], m->stage3, bytes, hipMemcpyDeviceToHost);
+            hipLaunchKernelGGL(pe_to_host_kernel<T>, dim3(1024), dim3(256), 0, s, m->stage3, B.st[set][f], W, H, L);
+            e = hipMemcpyAsync(out[f], m->stage3, bytes, hipMemcpyDeviceToHost, s);
         }
-        if (e != hipSuccess) {
-            *err = std::string("pe25d state transfer: ") + hipGetErrorString(e);
-            return GCM_ERR_HIP;
-        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        *err = std::string("pe25d state transfer: ") + hipGetErrorString(e);
+        return GCM_ERR_HIP;
     }
     return GCM_OK;
 }
 
 static int xfer(Pe25d *m, int set, bool to_dev, const double *const in[GCM_NFIELDS],
-                double *const out[GCM_NFIELDS], std::string *err) {
-    return m->f32 ? xfer_t<float>(m, set, to_dev, in, out, err) : xfer_t<double>(m, set, to_dev, in, out, err);
+                double *const out[GCM_NFIELDS], hipStream_t s, std::string *err) {
+    return m->f32 ? xfer_t<float>(m, set, to_dev, in, out, s, err) : xfer_t<double>(m, set, to_dev, in, out, s, err);
 }
 
 int pe25d_set(Pe25d *m, bool star, const double *p, const double *u, const double *v,
-              const double *t, const double *q, std::string *err) {
+              const double *t, const double *q, hipStream_t s, std::string *err) {
     const double *in[GCM_NFIELDS] = {p, u, v, t, q};
-    (void)hipDeviceSynchronize();
-    int rc = xfer(m, star ? 2 : m->cur_i, true, in, nullptr, err);
+    int rc = xfer(m, star ? 2 : m->cur_i, true, in, nullptr, s, err);
     if (rc == GCM_OK) m->star_valid = star;
     return rc;
 }
 
 int pe25d_get(Pe25d *m, bool star, double *p, double *u, double *v, double *t, double *q,
-              std::string *err) {
+              hipStream_t s, std::string *err) {
     if (star && !m->star_valid) {
         *err = "get_star: no predicted state yet";
         return GCM_ERR_STATE;
     }
     double *out[GCM_NFIELDS] = {p, u, v, t, q};
-    (void)hipDeviceSynchronize();
-    return xfer(m, star ? 2 : m->cur_i, false, nullptr, out, err);
+    return xfer(m, star ? 2 : m->cur_i, false, nullptr, out, s, err);
 }
 
 template <typename T>
@@ -1046,7 +1161,7 @@ static PeArgsT<T> make_args(Pe25d *m, int stage_set, int out_set, double dt) {
     a.p = B[GCM_P]; a.u = B[GCM_U]; a.v = B[GCM_V]; a.t = B[GCM_T]; a.q = B[GCM_Q];
     a.sp = S[GCM_P]; a.su = S[GCM_U]; a.sv = S[GCM_V]; a.st = S[GCM_T]; a.sq = S[GCM_Q];
     a.op = O[GCM_P]; a.ou = O[GCM_U]; a.ov = O[GCM_V]; a.ot = O[GCM_T]; a.oq = O[GCM_Q];
-    a.spu = Bf.spu; a.phi = Bf.phi; a.rho = Bf.rho; a.pgfu = Bf.pgfu;
+    a.spu = Bf.spu; a.phi = Bf.phi; a.pgfu = Bf.pgfu;
     a.pit = Bf.pit; a.pn = Bf.pn;
     a.part = Bf.part;
     a.part_stride = (long)rows_alloc(m) * m->W;
@@ -1267,7 +1382,7 @@ int pe25d_step_phase(Pe25d *m, int phase, double dt, hipStream_t s, std::string 
     return GCM_OK;
 }
 
-int pe25d_set_halo_buffers(Pe25d *m, void *north, void *south, std::string *err) {
+int pe25d_set_halo_buffers(Pe25d *m, void *north, void *south, hipStream_t s, std::string *err) {
     if (m->wrap) {
         *err = "set_halo_buffers: handle is not a latitude band";
         return GCM_ERR_STATE;
@@ -1276,7 +1391,8 @@ int pe25d_set_halo_buffers(Pe25d *m, void *north, void *south, std::string *err)
         *err = "set_halo_buffers: give both buffers, or neither to unregister";
         return GCM_ERR_ARG;
     }
-    (void)hipDeviceSynchronize();
+    (void)hipStreamSynchronize(s);
+    if (m->aux) (void)hipStreamSynchronize(m->aux);
     m->send_buf[0] = north;
     m->send_buf[1] = south;
     m->edges_pending = false;
@@ -1335,20 +1451,20 @@ int pe25d_halo_segments(Pe25d *m, bool pack, int side, void *dev_buf, SegCopy *c
     return GCM_OK;
 }
 
-int pe25d_ground(Pe25d *m, bool set, const double *in, double *out, std::string *err) {
+int pe25d_ground(Pe25d *m, bool set, const double *in, double *out, hipStream_t s, std::string *err) {
     const size_t bytes = sizeof(double) * (size_t)m->H * m->W;
-    (void)hipDeviceSynchronize();
     if (!m->gt) {
         void *d = nullptr;
-        if (hipMalloc(&d, bytes) != hipSuccess || hipMemset(d, 0, bytes) != hipSuccess) {
+        if (hipMalloc(&d, bytes) != hipSuccess || hipMemsetAsync(d, 0, bytes, s) != hipSuccess) {
             *err = "hip: ground temperature allocation failed";
             return GCM_ERR_HIP;
         }
         m->allocs.push_back(d);
         m->gt = (double *)d;
     }
-    hipError_t e = set ? hipMemcpy(m->gt, in, bytes, hipMemcpyHostToDevice)
-                       : hipMemcpy(out, m->gt, bytes, hipMemcpyDeviceToHost);
+    hipError_t e = set ? hipMemcpyAsync(m->gt, in, bytes, hipMemcpyHostToDevice, s)
+                       : hipMemcpyAsync(out, m->gt, bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { *err = "hip: ground temperature transfer failed"; return GCM_ERR_HIP; }
     return GCM_OK;
 }
@@ -1363,22 +1479,31 @@ static int radiation_launch(Pe25d *m, bool apply, double dt, double hour_angle, 
     r.tlw = m->rad_tab; r.tsw = r.tlw + L; r.csw_top = r.tsw + L; r.clw_b_div = r.csw_top + L; r.swfac = r.clw_b_div + L;
     r.coslat = m->rad_geo; r.sinlat = m->rad_geo + Hg; r.lon = m->rad_geo + 2 * Hg;
     r.gt = m->gt;
-    r.emis = B.spu; r.lwb = B.phi; r.ttp = B.rho; r.dTdt = B.pgfu; r.dtg = B.pit;
+    if (!B.rad_scr) {
+        T *d = nullptr;
+        if (!dev_upload<T>(m, &d, nullptr, (size_t)H * W * L)) { *err = "hip: radiation scratch allocation failed"; return GCM_ERR_HIP; }
+        B.rad_scr = d;
+    }
+    r.emis = B.spu; r.lwb = B.phi; r.ttp = B.rad_scr; r.dTdt = B.pgfu; r.dtg = B.pit;
     r.hour_angle = hour_angle;
     r.albedo = albedo; r.dt = dt; r.apply = apply ? 1 : 0;
     hipLaunchKernelGGL(pe_radiation_kernel<T>, dim3((W + 255) / 256, H), dim3(256), 0, s, a, r, B.st[m->cur_i][GCM_T]);
-    if (hipStreamSynchronize(s) != hipSuccess) { *err = "hip: radiation kernel failed"; return GCM_ERR_HIP; }
+    if (hipGetLastError() != hipSuccess) { *err = "hip: radiation kernel launch failed"; return GCM_ERR_HIP; }
+    // solar_timestep (apply) stays asynchronous on `s`; the diagnostics form copies its results back
     if (dtg_host) {
-        hipLaunchKernelGGL(pe_to_host_kernel<T>, dim3(64), dim3(256), 0, nullptr, m->stage3, B.pit, W, H, 1);
-        if (hipMemcpy(dtg_host, m->stage3, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost) != hipSuccess) {
+        hipLaunchKernelGGL(pe_to_host_kernel<T>, dim3(64), dim3(256), 0, s, m->stage3, B.pit, W, H, 1);
+        if (hipMemcpyAsync(dtg_host, m->stage3, sizeof(double) * (size_t)H * W, hipMemcpyDeviceToHost, s) != hipSuccess) {
             *err = "hip: dt_ground copy-back failed"; return GCM_ERR_HIP;
         }
     }
     if (dTdt_host) {
-        hipLaunchKernelGGL(pe_to_host_kernel<T>, dim3(1024), dim3(256), 0, nullptr, m->stage3, B.pgfu, W, H, L);
-        if (hipMemcpy(dTdt_host, m->stage3, sizeof(double) * (size_t)H * W * L, hipMemcpyDeviceToHost) != hipSuccess) {
+        hipLaunchKernelGGL(pe_to_host_kernel<T>, dim3(1024), dim3(256), 0, s, m->stage3, B.pgfu, W, H, L);
+        if (hipMemcpyAsync(dTdt_host, m->stage3, sizeof(double) * (size_t)H * W * L, hipMemcpyDeviceToHost, s) != hipSuccess) {
             *err = "hip: dTdt copy-back failed"; return GCM_ERR_HIP;
         }
+    }
+    if ((dtg_host || dTdt_host) && hipStreamSynchronize(s) != hipSuccess) {
+        *err = "hip: radiation kernel failed"; return GCM_ERR_HIP;
     }
     return GCM_OK;
 }
@@ -1389,11 +1514,11 @@ int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, do
                     hipStream_t s, std::string *err) {
     if (!m->gt) { *err = "radiation: set the ground temperature first (gcm_set_ground)"; return GCM_ERR_STATE; }
     if (!lat || !lon) { *err = "radiation: lat and lon tables are required"; return GCM_ERR_ARG; }
-    const int W = m->W, H = m->H, L = m->L, Hg = m->Hg;
-    (void)hipDeviceSynchronize();
+    const int W = m->W, L = m->L, Hg = m->Hg;
     if (m->rad_key[0] != t_lw || m->rad_key[1] != t_sw || !m->rad_tab) {
         // level tables, same expression order as grey_solar.py:323-333,377-385,541
-        std::vector<double> T((size_t)5 * L);
+        std::vector<double> &T = m->rad_tab_host;
+        T.assign((size_t)5 * L, 0.0);
         const std::vector<double> &dsig = m->dsig_host;
         double *tlw = T.data(), *tsw = tlw + L, *csw = tsw + L, *cdiv = csw + L, *swf = cdiv + L;
         for (int k = 0; k < L; ++k) {
@@ -1407,19 +1532,28 @@ int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, do
         if (!m->rad_tab && !dev_upload<double>(m, &m->rad_tab, nullptr, (size_t)5 * L)) {
             *err = "hip: radiation table allocation failed"; return GCM_ERR_HIP;
         }
-        if (hipMemcpy(m->rad_tab, T.data(), sizeof(double) * 5 * L, hipMemcpyHostToDevice) != hipSuccess) {
+        // the host copy lives in the handle until the next change, so the asynchronous upload may
+        // read it after this call returns; a change waits for the previous upload first
+        if (hipStreamSynchronize(s) != hipSuccess ||
+            hipMemcpyAsync(m->rad_tab, T.data(), sizeof(double) * 5 * L, hipMemcpyHostToDevice, s) != hipSuccess) {
             *err = "hip: radiation table upload failed"; return GCM_ERR_HIP;
         }
         m->rad_key[0] = t_lw; m->rad_key[1] = t_sw;
     }
-    {
-        std::vector<double> Gt((size_t)2 * Hg + W);
+    // lat / lon tables: uploaded when their content changes (normally once)
+    if (m->rad_latlon.size() != (size_t)Hg + W || memcmp(m->rad_latlon.data(), lat, sizeof(double) * Hg) ||
+        memcmp(m->rad_latlon.data() + Hg, lon, sizeof(double) * W)) {
+        if (hipStreamSynchronize(s) != hipSuccess) { *err = "hip: radiation geometry upload failed"; return GCM_ERR_HIP; }
+        m->rad_latlon.assign(lat, lat + Hg);
+        m->rad_latlon.insert(m->rad_latlon.end(), lon, lon + W);
+        std::vector<double> &Gt = m->rad_geo_host;
+        Gt.assign((size_t)2 * Hg + W, 0.0);
         for (int j = 0; j < Hg; ++j) { Gt[j] = std::cos(lat[j]); Gt[Hg + j] = std::sin(lat[j]); }
         for (int i = 0; i < W; ++i) Gt[2 * Hg + i] = lon[i];
         if (!m->rad_geo && !dev_upload<double>(m, &m->rad_geo, nullptr, Gt.size())) {
             *err = "hip: radiation geometry allocation failed"; return GCM_ERR_HIP;
         }
-        if (hipMemcpy(m->rad_geo, Gt.data(), sizeof(double) * Gt.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        if (hipMemcpyAsync(m->rad_geo, Gt.data(), sizeof(double) * Gt.size(), hipMemcpyHostToDevice, s) != hipSuccess) {
             *err = "hip: radiation geometry upload failed"; return GCM_ERR_HIP;
         }
     }
@@ -1428,34 +1562,58 @@ int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, do
                   : radiation_launch<double>(m, apply, dt, hour_angle, albedo, dTdt_host, dtg_host, s, err);
 }
 
-int pe25d_energy(Pe25d *m, const double *area_host, int area_len, double out[4], std::string *err) {
-    if (m->f32) { *err = "gcm_energy: fp64 handles only"; return GCM_ERR_UNSUPPORTED; }
-    if (!m->wrap) { *err = "gcm_energy: single band only"; return GCM_ERR_UNSUPPORTED; }
+// calc_energy + STATS in one launch and one synchronisation of `s`: out9 = u_max, u_min, v_max,
+// v_min, ke, ate, geo, total, NaN count.  The area table and the partials live in the handle.
+int pe25d_stats(Pe25d *m, const double *area_host, int area_len, double out[9], hipStream_t s, std::string *err) {
+    if (m->f32) { *err = "gcm_energy / gcm_stats: fp64 handles only"; return GCM_ERR_UNSUPPORTED; }
+    if (!m->wrap) { *err = "gcm_energy / gcm_stats: single band only"; return GCM_ERR_UNSUPPORTED; }
     if (!(area_len == 1 || area_len == m->W)) {
         *err = "gcm_energy: geom.area (H,) must broadcast against the last axis W (no_limits_2_5d.py:49): "
                "needs H == W or H == 1";
         return GCM_ERR_ARG;
     }
     const int gx = (m->W + 255) / 256, nb = gx * m->H;
-    double *d_area = nullptr, *d_out = nullptr;
-    if (hipMalloc((void **)&d_area, sizeof(double) * area_len) != hipSuccess ||
-        hipMalloc((void **)&d_out, sizeof(double) * 4 * nb) != hipSuccess ||
-        hipMemcpy(d_area, area_host, sizeof(double) * area_len, hipMemcpyHostToDevice) != hipSuccess) {
-        *err = "hip: gcm_energy allocation failed";
+    if (!m->stats_dev) {
+        if (!dev_upload<double>(m, &m->stats_dev, nullptr, (size_t)kStatsWords * nb + m->W)) {
+            *err = "hip: gcm_stats allocation failed";
+            return GCM_ERR_HIP;
+        }
+        m->stats_host.resize((size_t)kStatsWords * nb);
+    }
+    double *d_area = m->stats_dev + (size_t)kStatsWords * nb;
+    if (m->area_host.size() != (size_t)area_len || memcmp(m->area_host.data(), area_host, sizeof(double) * area_len)) {
+        m->area_host.assign(area_host, area_host + area_len);
+        if (hipMemcpyAsync(d_area, m->area_host.data(), sizeof(double) * area_len, hipMemcpyHostToDevice, s) != hipSuccess) {
+            *err = "hip: gcm_stats area upload failed";
+            return GCM_ERR_HIP;
+        }
+    }
+    PeArgs a = make_args<double>(m, m->cur_i, m->cur_i, 0.0);
+    hipLaunchKernelGGL(pe_energy_kernel, dim3(gx, m->H), dim3(256), 0, s, a, d_area, area_len > 1 ? 1 : 0, m->stats_dev);
+    double *part = m->stats_host.data();
+    if (hipMemcpyAsync(part, m->stats_dev, sizeof(double) * kStatsWords * nb, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        *err = "hip: gcm_stats kernel failed";
         return GCM_ERR_HIP;
     }
-    (void)hipDeviceSynchronize();
-    PeArgs a = make_args<double>(m, m->cur_i, m->cur_i, 0.0);
-    hipLaunchKernelGGL(pe_energy_kernel, dim3(gx, m->H), dim3(256), 0, nullptr, a, d_area, area_len > 1 ? 1 : 0, d_out);
-    std::vector<double> part((size_t)4 * nb);
-    hipError_t e = hipMemcpy(part.data(), d_out, sizeof(double) * 4 * nb, hipMemcpyDeviceToHost);
-    (void)hipFree(d_area);
-    (void)hipFree(d_out);
-    if (e != hipSuccess) { *err = "hip: gcm_energy kernel failed"; return GCM_ERR_HIP; }
-    double ke = 0, ate = 0, geo = 0;
-    for (int b = 0; b < nb; ++b) { ke += part[4 * b]; ate += part[4 * b + 1]; geo += part[4 * b + 2]; }
-    out[0] = ke; out[1] = ate; out[2] = geo; out[3] = ke + ate + geo;
+    double ke = 0, ate = 0, geo = 0, nn = 0, umax = -INFINITY, umin = INFINITY, vmax = -INFINITY, vmin = INFINITY;
+    for (int b = 0; b < nb; ++b) {
+        const double *o = part + (size_t)kStatsWords * b;
+        ke += o[0]; ate += o[1]; geo += o[2]; nn += o[7];
+        umax = std::fmax(umax, o[3]); umin = std::fmin(umin, o[4]);
+        vmax = std::fmax(vmax, o[5]); vmin = std::fmin(vmin, o[6]);
+    }
+    // np.max / np.min propagate NaN
+    out[0] = nn > 0 ? NAN : umax; out[1] = nn > 0 ? NAN : umin; out[2] = nn > 0 ? NAN : vmax; out[3] = nn > 0 ? NAN : vmin;
+    out[4] = ke; out[5] = ate; out[6] = geo; out[7] = ke + ate + geo; out[8] = nn;
     return GCM_OK;
+}
+
+// field geometry for get_total_variation (axis 0 of the reference layout): 2-D p differences rows,
+// the 3-D fields difference levels inside a row slab
+void pe25d_tv_shape(const Pe25d *m, int field, long *n_outer, long *n_axis, long *n_inner, int *wrap) {
+    if (field == GCM_P) { *n_outer = 1; *n_axis = m->H; *n_inner = m->W; *wrap = m->wrap ? 1 : 0; }
+    else { *n_outer = m->H; *n_axis = m->L; *n_inner = m->W; *wrap = 1; }
 }
 
 // current-state field for the diagnostics reductions; *f32 tells the element type

@@ -55,11 +55,10 @@ def calc_energy(p, u, v, t, q, g, geom):
 
 
 def _record(c, geom, stats):
-    stats["u_max"].append(c.diag(_lib.DIAG_MAX_U))
-    stats["u_min"].append(c.diag(_lib.DIAG_MIN_U))
-    stats["v_max"].append(c.diag(_lib.DIAG_MAX_V))
-    stats["v_min"].append(c.diag(_lib.DIAG_MIN_V))
-    stats["ke"].append(c.energy(geom.area))
+    """no_limits_2_5d.py:85-91: max/min of u and v and calc_energy, one fused device reduction"""
+    r = c.stats(geom.area)
+    for k in ("u_max", "u_min", "v_max", "v_min", "ke"):
+        stats[k].append(r[k])
 
 
 def full_timestep(p, u, v, t, q, g, dt, utc, geom, stats=STATS):

@@ -155,9 +155,19 @@ typedef enum {
     GCM_DIAG_MAX_U = 1,     /* np.max(u)                          constants.py:111-112          */
     GCM_DIAG_MEAN_P = 2,    /* np.mean(p)                         constants.py:111-112          */
     GCM_DIAG_SUM_P = 3,     /* conservation check                                                */
-    GCM_DIAG_MIN_U = 4, GCM_DIAG_MAX_V = 5, GCM_DIAG_MIN_V = 6  /* STATS, no_limits_2_5d.py:85-88 */
+    GCM_DIAG_MIN_U = 4, GCM_DIAG_MAX_V = 5, GCM_DIAG_MIN_V = 6, /* STATS, no_limits_2_5d.py:85-88 */
+    /* get_total_variation(field) = sum |q - roll(q, -1, 0)|  (constants.py:105-108), the monitor
+     * run_2d_with_ft evaluates every step (two_d.py:334-338).  Axis 0 of the REFERENCE layout: rows
+     * j for 2-D fields, levels k for the 3-D fields of GCM_PE25D.  On a latitude band the last row
+     * is differenced against the south ghost row (current after an exchange); the band sums add up
+     * to the global figure.                                                                       */
+    GCM_DIAG_TV_P = 7, GCM_DIAG_TV_U = 8, GCM_DIAG_TV_V = 9, GCM_DIAG_TV_T = 10, GCM_DIAG_TV_Q = 11
 } gcm_diag_kind;
 int gcm_diag(gcm_handle *h, int kind, double *out);
+/* The whole STATS record of full_timestep (no_limits_2_5d.py:85-91) by ONE launch and ONE
+ * synchronisation (GCM_PE25D, fp64, single band): out9 = u_max, u_min, v_max, v_min, ke, ate, geo,
+ * total (calc_energy, :35-60; `area` as gcm_energy), count of NaNs in u and v.                   */
+int gcm_stats(gcm_handle *h, const double *area, int area_len, double *out9);
 /* calc_energy(p,u,v,t,q,g,geom) -> out4 = (ke, ate, geo, total) in J, no_limits_2_5d.py:35-60
  * (GCM_PE25D).  `area` is geom.area; the reference broadcasts its (H,) array against the LAST
  * axis (:49), so area_len must be W (== H) or 1 -- reproduced, not fixed.                      */
@@ -238,6 +248,16 @@ int gcm_advect2d(int scheme, int axes, int finite, int width, int height, int ns
  * 2: pgf_templess (:248-261); 3: pressure_at_edge (:264-268).  out2 is [2][H][W].           */
 int gcm_pgf2d(int kind, int width, int height, double dt, double dx0, double dx1, const double *p,
               const double *t, double *out2);
+/* flux_limiter.py on 1-D arrays of n cells (host arrays in/out; ip/im = np.roll by -1/+1,
+ * coordinates_1d.py:25-30).  Results are BIT-identical to NumPy's, masks included: IEEE division,
+ * no contraction.
+ *   kind 0  van_leer(q)                    (r + |r|) / (1 + |r|)                       :10-11
+ *   kind 1  calc_r(q)                      (q - im(q)) / (ip(q) - q), 0 where the denominator == 0  :14-20
+ *   kind 2  donor_cell_flux(q, u)          where(u > 0, q, ip(q)) * u                  :23-27
+ *   kind 3  donor_cell_advection(q,u,dx,dt) q + (im(flux) - flux) * dt / dx            :30-32
+ * `u` is ignored by kinds 0 and 1 (may be NULL).                                                 */
+typedef enum { GCM_FL_VAN_LEER = 0, GCM_FL_CALC_R = 1, GCM_FL_DONOR_FLUX = 2, GCM_FL_DONOR_ADVECTION = 3 } gcm_fl_kind;
+int gcm_flux_limiter(int kind, int n, const double *q, const double *u, double dx, double dt, double *out);
 const char *gcm_ops_last_error(void);
 
 /* Timing helper for bench.py: runs nsteps steps bracketed by HIP events on the

@@ -304,7 +304,8 @@ def test_full_size_properties_c4(g):
     """BASELINE configs[3] size (1440x720x24), 3 steps: properties that do not need the oracle --
     sum(p) is conserved (the continuity equation is in flux form: the zonal term telescopes per
     row, the meridional one over the closed pole edge), the pole-edge v row is exactly zero
-    (dynamics.py:222), nothing goes non-finite, and bands == single domain."""
+    (dynamics.py:222), nothing goes non-finite.  (The oracle comparison at this size and
+    "8 bands == single domain" are in test_full_size_gpu.py.)"""
     from gcmiipy_amd import geometry
     H, W, L = 720, 1440, 24
     geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
