@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "fft_lds.h"
 #include "gcm_math.h"
@@ -136,6 +137,13 @@ __device__ __forceinline__ T conv_acc(T acc, T fx_hi, T fx_lo, T inv_dx, T sv_hi
 }
 template <typename T>
 __device__ __forceinline__ T sd_of(T rc, T pit, T sgb) { return fma(-pit, sgb, rc); }
+// kmh(q) sd: the flux of advec_sig (dynamics.py:50) through the face between two levels, a rounded
+// product (no contraction), so that it can be carried from the level above instead of recomputed
+template <typename T>
+__device__ __forceinline__ T face_flux_v(T q_a, T q_b, T sd) {
+#pragma clang fp contract(off)
+    return ((q_a + q_b) * T(0.5)) * sd;
+}
 
 // Density and geopotential are NOT kept in HBM level by level.  pe_geopot_kernel stores phi on
 // the even levels only (the anchors); the filter kernel K3 and the update kernel K4 rebuild rho on
@@ -591,6 +599,326 @@ __global__ __launch_bounds__(kUpdThreads) void pe_update_kernel(PeArgsT<T> a) {
     }
 }
 
+// ---------------------------------------------------------------- K4, row-group form
+// A workgroup is R compute waves = R consecutive rows x 62 columns (lanes 1..62; lanes 0 and 63
+// carry the halo columns i-1 / i+1 and are not stored) plus ONE loader wave, marching the levels
+// top-down in lockstep.  Everything the march reads from global memory goes through LDS tiles, one
+// per level, [field][row slot][lane]:
+//   * at the top of the iteration of level k every compute wave REQUESTS its own row of level k-3
+//     (su, sv, st, sq, spu, the phi anchor, pgfu, the base state) and the loader wave the two halo
+//     rows (above and below the group); the requests of the previous iteration (level k-2) are
+//     written to their tile at the END of the iteration, one barrier per level.  A request thus has
+//     two levels of arithmetic to arrive, and the only reader of a requested register is that tile
+//     write, so the compiler's in-order vmcnt wait leaves the newest requests in flight;
+//   * the iteration reads the tiles of level k (own row, rows j-1 / j+1) and k-1 (the level below:
+//     vertical fluxes, the south theta of the geopotential anchor); three tiles rotate;
+//   * columns i-1 / i+1 of the own row come from the neighbouring lanes (DPP);
+//   * sigma-dot at (j, i+1) is the east lane's value (DPP); at (j+1, i) it is rebuilt from the tile;
+//   * the fluxes through the upper faces are the lower-face fluxes of the level above, carried.
+// A row of the stage state leaves HBM (R+2)/R times instead of up to three times.
+constexpr int kUpdCols = 62;
+__device__ __forceinline__ float from_west(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
+}
+// slots of one level tile, in units of 64 lanes
+template <int R> struct UpdTile {
+    static constexpr int kMain = 0;                      // su, sv, st, sq, spu: R+2 slots each (0 = row above the group)
+    static constexpr int kPhi = 5 * (R + 2);             // phi anchor: R+1 slots (own rows, then the row below the group)
+    static constexpr int kOwn = kPhi + R + 1;            // pgfu, u, v, t, q of the base state: R slots each
+    static constexpr int kSlots = kOwn + 5 * R;
+};
+// SAME: the stage state is the base state (predictor): no base-state requests
+template <typename T, int R, bool SAME>
+__global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T> a) {
+    using TL = UpdTile<R>;
+    extern __shared__ unsigned char upd_lds_raw[];
+    __shared__ double tab[kExnerTabDoubles];
+    // the level tables go to LDS too: read from global memory inside the march, their waits (vmcnt
+    // counts in order) would also wait for every request still in flight
+    T *lv_sig = (T *)upd_lds_raw, *lv_dsig = lv_sig + a.L, *lv_inv_dsig = lv_dsig + a.L, *lv_sigb = lv_inv_dsig + a.L;
+    T *tile = lv_sigb + a.L + 1;                     // one word of slack on either side: lane -1 / 64 reads
+    for (int n = threadIdx.x; n < kExnerTabDoubles; n += 64 * (R + 1)) tab[n] = a.exner_tab[n];
+    for (int n = threadIdx.x; n < a.L; n += 64 * (R + 1)) {
+        lv_sig[n] = a.sig[n]; lv_dsig[n] = a.dsig[n]; lv_inv_dsig[n] = a.inv_dsig[n]; lv_sigb[n] = a.sigb[n];
+    }
+    __syncthreads();
+    const Idx ix{a.W, a.H, a.L, a.wrap};
+    const int W = a.W, L = a.L;
+    const int ncol = (W + kUpdCols - 1) / kUpdCols;
+    const int per_xcd = gridDim.x / 8;
+    const int wg = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    // wg = ((row group, level segment), column tile); groups come from [j0, j1) then [jb0, jb1)
+    const int nseg = a.nseg;
+    const int rowseg = wg / ncol, ct = wg - rowseg * ncol;
+    const int grp = rowseg / nseg, seg = rowseg - grp * nseg;
+    const int na = a.j1 - a.j0, nb = a.jb1 - a.jb0;
+    const int ga = (na + R - 1) / R, gb = (nb + R - 1) / R;
+    if (grp >= ga + gb) return;                                  // padding workgroups (uniform)
+    const int jg = grp < ga ? a.j0 + grp * R : a.jb0 + (grp - ga) * R;
+    const int jend = min(jg + R, grp < ga ? a.j1 : a.jb1);
+    const int nact = jend - jg;
+    const int k_lo = seg_lo(seg, nseg, L), k_hi = seg_lo(seg + 1, nseg, L);
+    if (k_hi <= k_lo) return;                                    // uniform
+    const int r = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    constexpr int kBuf = TL::kSlots * 64;
+    const int iraw = ct * kUpdCols + lane - 1;
+    const int i = wrapi(iraw, W), ie = i + 1 == W ? 0 : i + 1;
+    const int k0 = k_hi - 1;
+    const int kmin = k_lo > 0 ? k_lo - 1 : 0;                    // tiles exist for levels k0 .. kmin
+    constexpr bool same = SAME;
+    T *const t0 = tile + lane;
+    // tile of the level at distance d below k0: buffers rotate 0, 1, 2
+    int bc = 0, bm = 1, bf = 2;                                  // level k, k-1, k-2 (being filled)
+
+    if (r == R) {
+        // ---- loader wave: the halo rows jg-1 (slot 0) and jend (slot nact+1; its phi anchor: slot nact)
+        const long rn = ix.r3(jg - 1), rs = ix.r3(jend);
+        const int ss = nact + 1;
+        T h[2][10];
+        const auto load = [&](T (&d)[10], int k) {
+            const long kl = (long)k * W;
+            d[0] = a.su[rn + kl + i]; d[1] = a.sv[rn + kl + i]; d[2] = a.st[rn + kl + i]; d[3] = a.sq[rn + kl + i];
+            d[4] = a.su[rs + kl + i]; d[5] = a.sv[rs + kl + i]; d[6] = a.st[rs + kl + i]; d[7] = a.sq[rs + kl + i];
+            d[8] = a.spu[rs + kl + i]; d[9] = a.phi[rs + kl + i];
+        };
+        const auto put = [&](const T (&d)[10], int buf) {
+            T *t = t0 + buf * kBuf;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) t[(TL::kMain + f * (R + 2)) * 64] = d[f];
+#pragma unroll
+            for (int f = 0; f < 5; ++f) t[(TL::kMain + f * (R + 2) + ss) * 64] = d[4 + f];
+            t[(TL::kPhi + nact) * 64] = d[9];
+        };
+        load(h[0], k0);
+        put(h[0], 0);
+        if (k0 - 1 >= kmin) { load(h[1], k0 - 1); put(h[1], 1); }
+        // requests are unconditional (level clamped to kmin): a conditional one would make the compiler
+        // size its in-order vmcnt waits for the path without it, i.e. wait for the newest requests too
+        load(h[0], max(k0 - 2, kmin));
+        __syncthreads();
+        for (int k = k0;;) {
+            load(h[1], max(k - 3, kmin));
+            if (k - 2 >= kmin) put(h[0], bf);
+            if (k == k_lo) break;
+            __syncthreads();
+            { const int t = bc; bc = bm; bm = bf; bf = t; }
+            --k;
+            load(h[0], max(k - 3, kmin));
+            if (k - 2 >= kmin) put(h[1], bf);
+            if (k == k_lo) break;
+            __syncthreads();
+            { const int t = bc; bc = bm; bm = bf; bf = t; }
+            --k;
+        }
+        return;
+    }
+    if (r >= nact) {                                             // rows past the range: keep the barriers
+        for (int k = k0; k >= k_lo; --k) __syncthreads();
+        return;
+    }
+    const int j = jg + r;
+    const bool store = lane >= 1 && lane <= kUpdCols && iraw < W;
+    const int jg_row = wrapi(a.row0 + j, a.Hg);
+    const T inv_dxj = a.inv_dxj[jg_row], inv_dxh = a.inv_dxh[jg_row], inv_dy = a.inv_dy, dt = a.dt;
+    const T inv_dxj_s = a.inv_dxj[wrapi(a.row0 + j + 1, a.Hg)];
+    const long rc = ix.r3(j);
+    const T *spr = a.sp;
+    const long p_n = ix.r2(j - 1), p_c = ix.r2(j), p_s = ix.r2(j + 1), p_ss = ix.r2(j + 2);
+    const T sp_c = spr[p_c + i], sp_e = spr[p_c + ie];
+    const T sp_s = spr[p_s + i], sp_se = spr[p_s + ie], sp_ss = spr[p_ss + i];
+    const T sp_n = spr[p_n + i], sp_ne = spr[p_n + ie];
+    const T jph_c = (sp_c + sp_s) * T(0.5), jph_ce = (sp_e + sp_se) * T(0.5);
+    const T jph_n = (sp_n + sp_c) * T(0.5), jph_ne = (sp_ne + sp_e) * T(0.5);
+    const T jph_s = (sp_s + sp_ss) * T(0.5);
+    const T pb_c = a.p[p_c + i], pb_e = a.p[p_c + ie], pb_s = a.p[p_s + i];
+    const T iph_pb = (pb_c + pb_e) * T(0.5), jph_pb = (pb_c + pb_s) * T(0.5);
+    const T pn_c = a.pn[p_c + i], pn_e = a.pn[p_c + ie], pn_s = a.pn[p_s + i];
+    const T inv_pnu = rcp((pn_c + pn_e) * T(0.5)), inv_pnv = rcp((pn_c + pn_s) * T(0.5)), inv_pn = rcp(pn_c);
+    const bool pole_edge = jg_row == a.Hg - 1;
+    const bool coriolis = a.cor_u != nullptr;
+    const T cp_u = coriolis ? a.cor_u[jg_row] : T(0.0), cp_v = coriolis ? a.cor_v[jg_row] : T(0.0);
+    if (seg == 0 && store) a.op[(long)j * W + i] = pn_c;
+    const T pit_c = a.pit[p_c + i], pit_s = a.pit[p_s + i];
+    const T ptop = a.ptop;
+
+    // own-row requests of one level: su, sv, st, sq, spu, phi anchor, pgfu, base u, v, t, q
+    T q[2][11];
+    const auto load = [&](T (&d)[11], int k) {
+        const long o = rc + (long)k * W + i;
+        d[0] = a.su[o]; d[1] = a.sv[o]; d[2] = a.st[o]; d[3] = a.sq[o]; d[4] = a.spu[o]; d[5] = a.phi[o]; d[6] = a.pgfu[o];
+        if (!same) { d[7] = a.u[o]; d[8] = a.v[o]; d[9] = a.t[o]; d[10] = a.q[o]; }
+    };
+    const auto put = [&](const T (&d)[11], int buf) {
+        T *t = t0 + buf * kBuf;
+#pragma unroll
+        for (int f = 0; f < 5; ++f) t[(TL::kMain + f * (R + 2) + 1 + r) * 64] = d[f];
+        t[(TL::kPhi + r) * 64] = d[5];
+        t[(TL::kOwn + r) * 64] = d[6];
+        if (!same) {
+#pragma unroll
+            for (int f = 1; f < 5; ++f) t[(TL::kOwn + f * R + r) * 64] = d[6 + f];
+        }
+    };
+    // running sums of conv from the top; fluxes kmh(q) sd through the upper face of level k0
+    // (advec_sig, dynamics.py:49-52): zero at the top of the column (sd wraps to sd[0] = 0), else
+    // rebuilt from level k_hi exactly as the iteration of level k_hi forms its lower-face fluxes
+    // (face_flux_v), so a segmented march gives the same bits
+    T rc_c = T(0.0), rc_s = T(0.0);
+    T fu_up = T(0.0), fv_up = T(0.0), ft_up = T(0.0), fq_up = T(0.0);
+    load(q[0], k0);
+    if (k_hi < L) {
+        const T *part = a.part + (long)seg * a.part_stride;
+        const T sgb_hi = lv_sigb[k_hi];
+        rc_c = part[p_c + i]; rc_s = part[p_s + i];
+        const T sd_cp = sd_of(rc_c, pit_c, sgb_hi), sd_sp = sd_of(rc_s, pit_s, sgb_hi);
+        const T sd_ep = from_east(sd_cp);
+        const long kp0 = (long)k_hi * W;
+        fu_up = face_flux_v(a.su[rc + kp0 + i], q[0][0], (sd_cp + sd_ep) * T(0.5));
+        fv_up = face_flux_v(a.sv[rc + kp0 + i], q[0][1], (sd_cp + sd_sp) * T(0.5));
+        ft_up = face_flux_v(a.st[rc + kp0 + i], q[0][2], sd_cp);
+        fq_up = face_flux_v(a.sq[rc + kp0 + i], q[0][3], sd_cp);
+    }
+    put(q[0], 0);
+    if (k0 - 1 >= kmin) { load(q[1], k0 - 1); put(q[1], 1); }
+    load(q[0], max(k0 - 2, kmin));                               // unconditional, clamped: see the loader wave
+    // geopotential anchors (see phi_up): an odd level k steps up from the anchor phi[k-1] (tile of
+    // level k-1) and leaves the level k-1 exner factors, anchors and south theta to the even level below
+    bool have_lo = false;
+    T lo_ex_c = T(0.0), lo_ex_s = T(0.0), lo_phi_c = T(0.0), lo_phi_s = T(0.0), lo_st_s = T(0.0);
+    __syncthreads();
+    const auto level = [&](const int k) __attribute__((always_inline)) {
+        const long kc = (long)k * W;
+        const T *tc = t0 + bc * kBuf, *tm = t0 + bm * kBuf;
+        const auto own = [&](const T *t, int f) { return t[(TL::kMain + f * (R + 2) + 1 + r) * 64]; };
+        const auto nrow = [&](const T *t, int f) { return t + (TL::kMain + f * (R + 2) + r) * 64; };
+        const auto srow = [&](const T *t, int f) { return t + (TL::kMain + f * (R + 2) + 2 + r) * 64; };
+        const T su_c = own(tc, 0), sv_c = own(tc, 1), st_c = own(tc, 2), sq_c = own(tc, 3), spu_c = own(tc, 4);
+        // ---- neighbours: own row by lane shifts, rows j-1 / j+1 from the tile
+        const T su_w = from_west(su_c), su_e = from_east(su_c);
+        const T sv_w = from_west(sv_c), sv_e = from_east(sv_c);
+        const T spu_w = from_west(spu_c), spu_e = from_east(spu_c);
+        const T st_w = from_west(st_c), st_e = from_east(st_c);
+        const T sq_w = from_west(sq_c), sq_e = from_east(sq_c);
+        const T su_n = *nrow(tc, 0), sv_n = *nrow(tc, 1), sv_ne = nrow(tc, 1)[1], st_n = *nrow(tc, 2), sq_n = *nrow(tc, 3);
+        const T su_s = *srow(tc, 0), sv_s = *srow(tc, 1), st_sl = *srow(tc, 2), sq_s = *srow(tc, 3);
+        const T spu_s = *srow(tc, 4), spu_sw = srow(tc, 4)[-1];
+        const T spv_c = sv_c * jph_c, spv_e = sv_e * jph_ce;
+        const T spv_n = sv_n * jph_n, spv_ne = sv_ne * jph_ne;
+        const T spv_s = sv_s * jph_s;
+        // ---- aflux, dynamics.py:35-46, at (j,i) and (j+1,i); (j,i+1) is the east lane's
+        const T dsg = lv_dsig[k], sgb = lv_sigb[k];
+        T sd_c = T(0.0), sd_s = T(0.0);                           // sd[0] = 0, dynamics.py:44
+        if (k > 0) {
+            rc_c = conv_acc(rc_c, spu_c, spu_w, inv_dxj, sv_c, jph_c, sv_n, jph_n, inv_dy, dsg);
+            rc_s = conv_acc(rc_s, spu_s, spu_sw, inv_dxj_s, sv_s, jph_s, sv_c, jph_c, inv_dy, dsg);
+            sd_c = sd_of(rc_c, pit_c, sgb);
+            sd_s = sd_of(rc_s, pit_s, sgb);
+        }
+        const T sd_e = from_east(sd_c);
+        // ---- advec_m_pu, dynamics.py:55-108
+        const T puum = ((su_c + su_w) * T(0.5)) * ((spu_c + spu_w) * T(0.5));
+        const T puup = ((su_e + su_c) * T(0.5)) * ((spu_e + spu_c) * T(0.5));
+        const T puvp = ((spv_c + spv_e) * T(0.5)) * ((su_c + su_s) * T(0.5));
+        const T puvm = ((spv_n + spv_ne) * T(0.5)) * ((su_n + su_c) * T(0.5));
+        const T pvvm = ((sv_c + sv_n) * T(0.5)) * ((spv_c + spv_n) * T(0.5));
+        const T pvvp = ((sv_s + sv_c) * T(0.5)) * ((spv_s + spv_c) * T(0.5));
+        const T pvup = ((sv_c + sv_e) * T(0.5)) * ((spu_c + spu_s) * T(0.5));
+        const T pvum = ((sv_w + sv_c) * T(0.5)) * ((spu_w + spu_sw) * T(0.5));
+        T cor_u = T(0.0), cor_v = T(0.0);                         // the reference adds a literal 0
+        if (coriolis) {                                          // dynamics.py:83-92
+            const T pu_at_pv = (((spu_c + spu_s) * T(0.5)) + ((spu_w + spu_sw) * T(0.5))) * T(0.5);    // imh(jph(pu))
+            const T pv_at_pu = (((spv_c + spv_n) * T(0.5)) + ((spv_e + spv_ne) * T(0.5))) * T(0.5);    // iph(jmh(pv))
+            cor_u = cp_u * -pv_at_pu;
+            cor_v = cp_v * pu_at_pv;
+        }
+        const T dut = (puum - puup) * inv_dxj + (puvm - puvp) * inv_dy + cor_u;
+        const T dvt = (pvvm - pvvp) * inv_dy + (pvum - pvup) * inv_dxh + cor_v;
+        // ---- advec_t for t and q, dynamics.py:174-181
+        const T adt = (spu_c * ((st_c + st_e) * T(0.5)) - spu_w * ((st_w + st_c) * T(0.5))) * inv_dxj +
+                      (spv_c * ((st_c + st_sl) * T(0.5)) - spv_n * ((st_n + st_c) * T(0.5))) * inv_dy;
+        const T adq = (spu_c * ((sq_c + sq_e) * T(0.5)) - spu_w * ((sq_w + sq_c) * T(0.5))) * inv_dxj +
+                      (spv_c * ((sq_c + sq_s) * T(0.5)) - spv_n * ((sq_n + sq_c) * T(0.5))) * inv_dy;
+        // ---- the level below (k-1), from its tile: vertical fluxes and the anchor step.  At k == 0 the
+        //      lower face carries sd[0] = 0: any finite value serves
+        T su_m = su_c, sv_m = sv_c, st_m = st_c, sq_m = sq_c;
+        if (k > 0) { su_m = own(tm, 0); sv_m = own(tm, 1); st_m = own(tm, 2); sq_m = own(tm, 3); }
+        // ---- pgf v-part, dynamics.py:160,167-169: rho and phi of (j,i) and (j+1,i) rebuilt (rho_of / phi_up)
+        const T sg = lv_sig[k];
+        T ex_c, ex_s, phi_c, phi_s, st_s;
+        if (have_lo) {
+            ex_c = lo_ex_c; ex_s = lo_ex_s; phi_c = lo_phi_c; phi_s = lo_phi_s; st_s = lo_st_s;
+        } else {
+            ex_c = exner(sp_c * sg + ptop, tab);
+            ex_s = exner(sp_s * sg + ptop, tab);
+            st_s = st_sl;
+            phi_c = tc[(TL::kPhi + r) * 64]; phi_s = tc[(TL::kPhi + r + 1) * 64];   // an even level's own anchor (unused when k is odd)
+        }
+        have_lo = (k & 1) != 0;
+        if (have_lo) {                                            // k odd: level k-1 >= 0 is the anchor
+            const T sg_lo = lv_sig[k - 1];
+            lo_ex_c = exner(sp_c * sg_lo + ptop, tab);
+            lo_ex_s = exner(sp_s * sg_lo + ptop, tab);
+            lo_st_s = *srow(tm, 2); lo_phi_c = tm[(TL::kPhi + r) * 64]; lo_phi_s = tm[(TL::kPhi + r + 1) * 64];
+            phi_c = phi_up(lo_phi_c, st_m, st_c, lo_ex_c, ex_c);
+            phi_s = phi_up(lo_phi_s, lo_st_s, st_s, lo_ex_s, ex_s);
+        }
+        const T rho_c = rho_of(sp_c * sg + ptop, st_c, ex_c), rho_s = rho_of(sp_s * sg + ptop, st_s, ex_s);
+        const T phiv = jph_c * ((phi_s - phi_c) * inv_dy);
+        const T pgv = ((sg * sp_c + sg * sp_s) * T(0.5)) * rcp((rho_c + rho_s) * T(0.5)) * ((sp_s - sp_c) * inv_dy);
+        // ---- vertical advection, dynamics.py:49-52 with iph(sd), jph(sd), sd
+        const T inv_ds = lv_inv_dsig[k];
+        const T fu = face_flux_v(su_c, su_m, (sd_c + sd_e) * T(0.5)), fv = face_flux_v(sv_c, sv_m, (sd_c + sd_s) * T(0.5));
+        const T ft = face_flux_v(st_c, st_m, sd_c), fq = face_flux_v(sq_c, sq_m, sd_c);
+        const T dus = -((fu - fu_up) * inv_ds);
+        const T dvs = -((fv - fv_up) * inv_ds);
+        const T dts = -((ft - ft_up) * inv_ds);
+        const T dqs = -((fq - fq_up) * inv_ds);
+        fu_up = fu; fv_up = fv; ft_up = ft; fq_up = fq;
+        // ---- momentum, theta and q update, dynamics.py:186-219 (predictor: the stage state IS the base state)
+        const T pgfu_c = tc[(TL::kOwn + r) * 64];
+        T bu_c = su_c, bv_c = sv_c, bt_c = st_c, bq_c = sq_c;
+        if (!same) {
+            bu_c = tc[(TL::kOwn + R + r) * 64]; bv_c = tc[(TL::kOwn + 2 * R + r) * 64];
+            bt_c = tc[(TL::kOwn + 3 * R + r) * 64]; bq_c = tc[(TL::kOwn + 4 * R + r) * 64];
+        }
+        const T pu = bu_c * iph_pb;
+        const T pv = bv_c * jph_pb;
+        const T pu_n = pu - (dut + dus + pgfu_c) * dt;
+        const T pv_n = pv - (dvt + dvs + phiv + pgv) * dt;
+        T u_n = pu_n * inv_pnu;
+        T v_n = pv_n * inv_pnv;
+        if (pole_edge) v_n *= T(0.0);                               // v_n[:, -1, :] *= 0, dynamics.py:222
+        const T t_n = (bt_c * pb_c - (adt + dts) * dt) * inv_pn;
+        const T q_n = (bq_c * pb_c - (adq + dqs) * dt) * inv_pn;
+        if (store) {
+            const long o = (long)j * L * W + kc + i;             // rows to produce are interior: no wrap
+            a.ou[o] = u_n;
+            a.ov[o] = v_n;
+            a.ot[o] = t_n;
+            a.oq[o] = q_n;
+        }
+    };
+    // two request sets that swap BY NAME (loop unrolled by two): a register copy of a value still in
+    // flight would make the wave wait for it at once
+    for (int k = k0;;) {
+        load(q[1], max(k - 3, kmin));
+        level(k);
+        if (k - 2 >= kmin) put(q[0], bf);
+        if (k == k_lo) break;
+        __syncthreads();
+        { const int t = bc; bc = bm; bm = bf; bf = t; }
+        --k;
+        load(q[0], max(k - 3, kmin));
+        level(k);
+        if (k - 2 >= kmin) put(q[1], bf);
+        if (k == k_lo) break;
+        __syncthreads();
+        { const int t = bc; bc = bm; bm = bf; bf = t; }
+        --k;
+    }
+}
+
 using PeArgs = PeArgsT<double>;   // the diagnostics and the column physics below are fp64 only
 
 // ---------------------------------------------------------------- calc_energy + STATS (no_limits_2_5d.py:35-60,85-91)
@@ -781,6 +1109,7 @@ struct Pe25d {
     int cur_i = 0;
     bool star_valid = false;
     int nseg = 1;                               // level segments of K4, chosen from the band's size
+    int upd_rows = 7;                           // rows per workgroup of the row-group K4 (0: one-wave form)
     int pack_set = -1;                          // >= 0: state set gcm_halo_pack reads (step_phase)
     double *stage3 = nullptr;                   // float64 transpose staging, host layout
     double *exner_tab = nullptr;
@@ -859,6 +1188,8 @@ static FilterKernel<T> pgf_filter_kernel_for(const SuperPlan &P) {
     return pe_pgf_filter_kernel<T, 25>;
 }
 template <typename T>
+static size_t upd_lds_bytes(int R, int L) { return sizeof(T) * ((size_t)3 * (11 * R + 11) * 64 + 2 + 4 * (size_t)L); }
+template <typename T>
 static size_t filter_lds_bytes(const Pe25d *m) {
     return (size_t)(m->cplan.ok ? 1 : 2) * m->W * sizeof(typename Vec2<T>::type);
 }
@@ -934,7 +1265,15 @@ static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
         hipFuncSetAttribute((const void *)pgf_filter_kernel_for<T>(m->cplan), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)filter_lds_bytes<T>(m)) != hipSuccess ||
         hipFuncSetAttribute((const void *)pe_geopot_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(L * kColThreads * sizeof(T))) != hipSuccess)
+                            (int)(L * kColThreads * sizeof(T))) != hipSuccess ||
+        hipFuncSetAttribute((const void *)pe_update_rows_kernel<T, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)upd_lds_bytes<T>(7, L)) != hipSuccess ||
+        hipFuncSetAttribute((const void *)pe_update_rows_kernel<T, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)upd_lds_bytes<T>(7, L)) != hipSuccess ||
+        hipFuncSetAttribute((const void *)pe_update_rows_kernel<T, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)upd_lds_bytes<T>(3, L)) != hipSuccess ||
+        hipFuncSetAttribute((const void *)pe_update_rows_kernel<T, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)upd_lds_bytes<T>(3, L)) != hipSuccess)
         return "dynamic LDS size";
     return nullptr;
 }
@@ -1063,6 +1402,10 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
         const long tiles = (long)((W + kUpdThreads - 1) / kUpdThreads) * m->H;
         long want = (5L * 8 * cus / 2 + tiles - 1) / tiles;
         if (const char *e = getenv("GCM_PE_LEVEL_SEGMENTS")) want = atoi(e);
+        if (const char *e = getenv("GCM_PE_UPDATE_ROWS")) {      // 0: the one-wave update kernel; 3, 7: rows per group
+            const int v = atoi(e);
+            m->upd_rows = (v == 0 || v == 3 || v == 7) ? v : 7;
+        }
         const int cap = std::min(kMaxSeg, std::max(1, L / 4));
         m->nseg = (int)std::max(1L, std::min((long)cap, want));
     }
@@ -1238,6 +1581,19 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         a.j1 = std::max(r0, r1);
         a.jb0 = rb0;
         a.jb1 = std::max(rb0, rb1);
+        if (m->upd_rows > 0) {
+            const int Rg = m->upd_rows;
+            const long groups = (std::max(0, r1 - r0) + Rg - 1) / Rg + (std::max(0, rb1 - rb0) + Rg - 1) / Rg;
+            const long wgs = (long)((W + kUpdCols - 1) / kUpdCols) * groups * a.nseg;
+            const dim3 gg((unsigned)((wgs + 7) / 8 * 8));
+            const size_t lds = upd_lds_bytes<T>(Rg, L);
+            const bool same = a.u == a.su;
+            if (Rg == 7 && same) hipLaunchKernelGGL((pe_update_rows_kernel<T, 7, true>), gg, dim3(64 * 8), lds, st, a);
+            else if (Rg == 7) hipLaunchKernelGGL((pe_update_rows_kernel<T, 7, false>), gg, dim3(64 * 8), lds, st, a);
+            else if (same) hipLaunchKernelGGL((pe_update_rows_kernel<T, 3, true>), gg, dim3(64 * 4), lds, st, a);
+            else hipLaunchKernelGGL((pe_update_rows_kernel<T, 3, false>), gg, dim3(64 * 4), lds, st, a);
+            return;
+        }
         const long tiles = (long)((W + kUpdThreads - 1) / kUpdThreads) * rows * a.nseg;
         hipLaunchKernelGGL(pe_update_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kUpdThreads), 0, st, a);
     };
