@@ -3,7 +3,11 @@
 HBM roofline (BASELINE.json).  One "step" = one full Matsuno step (predictor +
 corrector, every prognostic field read once and written once) over the whole grid.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4] [--only]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5|c5_phys...] [--only]
+
+The timed region is a block of EXACTLY K steps between barrier + synchronize fences; the block is
+repeated until at least MIN_TIMED_S seconds have been timed and the MEDIAN block is reported
+(`ms_per_step`, `value`), with the fastest and slowest block beside it (`ms_per_step_min/max`).
 
 The headline workload is c3 (BASELINE configs[2], 4096x2048 shallow water + theta +
 viscosity + van-Leer tracer, fp64).  N > 1 is launched by torch.distributed.run, one rank
@@ -26,6 +30,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SETTLE_S = float(os.environ.get("GCM_BENCH_SETTLE_S", "0.15"))   # untimed pre-conditioning before warm-up (see run_workload)
+MIN_TIMED_S = float(os.environ.get("GCM_BENCH_MIN_TIMED_S", "0.5"))   # the K-step block is repeated until this much is timed
+MAX_BLOCKS = 400
+PROFILE_ROUND = "r02"     # profiles/<round>/traffic.json: PMC passes of this same command (tools/tools_prof.sh)
 
 WORKLOADS = {
     # name: (description, H, W, L, model, tracer, bytes per cell-update = 2 * fields * 8, dt)
@@ -45,7 +52,15 @@ WORKLOADS = {
            1440, 2880, 40, "PE25D", None, 64.0 + 16.0 / 40, 1.0),
     "c5_f32": ("2.5-D sigma-level primitive equations, 2880x1440x40 fp32 (BASELINE configs[4] grid)",
                1440, 2880, 40, "PE25D", None, 32.0 + 8.0 / 40, 1.0),
+    # BASELINE configs[4] as a workload: every step = the dynamics (with the humidity tracer q) + the grey
+    # radiation / solar_timestep column physics (grey_solar.py:358-563, no_limits_2_5d.py:66-75).  The
+    # physics pass reads and writes theta once more (+16 B per cell) and the 2-D ground temperature.
+    "c5_phys": ("2.5-D primitive equations + grey_solar radiation + humidity tracer, 2880x1440x40 fp64 "
+                "(BASELINE configs[4])", 1440, 2880, 40, "PE25D", None, 80.0 + 32.0 / 40, 1.0),
+    "c5_phys_f32": ("2.5-D primitive equations + grey_solar radiation + humidity tracer, 2880x1440x40 fp32 "
+                    "(BASELINE configs[4])", 1440, 2880, 40, "PE25D", None, 40.0 + 16.0 / 40, 1.0),
 }
+PHYS_UTC0 = 6 * 3600.0
 ALSO = ("c2", "c3", "c4", "c4_f32")     # secondary workloads of the default run
 DX = 300e3
 
@@ -81,20 +96,38 @@ def cpu_baseline(name):
     from oracle import sw2d, sw2d_temp, tracer
     _, H, W, L, _, _, _, dt = WORKLOADS[name]
     if WORKLOADS[name][4] == "PE25D":
-        # bounded sample: the same recipe on a 360x180x24 grid (1/16 of the cells), 2 steps
-        from oracle import dynamics, geometry as ogeo
-        h, w = 180, 360
-        og = ogeo.gen_geometry(h, w, L, sig_func=ogeo.manabe_sig)
-        s = synth(name, h, w, L, geom=og)
-        st = (s["p"], s["u"], s["v"], s["t"], s["q"])
+        from oracle import dynamics, geometry as ogeo, physics
+        import copy
+        og = ogeo.gen_geometry(H, W, L, sig_func=ogeo.manabe_sig)
+        phys = "phys" in name
+        if H * W * L <= 30e6:
+            # the configured grid itself (c4: 2 steps, ~10 s each on one core)
+            rows, nst, what = slice(0, H), 2, "%d full steps of the %dx%dx%d grid" % (2, W, H, L)
+            sg = og
+        else:
+            # bounded sample of the configured grid: a latitude strip of FULL width and depth (the cost of a
+            # step is per row: FFT rows of W, column scans of L), 90 mid-latitude rows, same recipe
+            rows, nst = slice(H // 4, H // 4 + 90), 2
+            what = "%d steps of a 90-row latitude strip of the %dx%dx%d grid (full width and depth)" % (nst, W, H, L)
+            sg = copy.copy(og)
+            sg.height = 90
+            sg.dx_j, sg.dx_h = og.dx_j[:, rows, :], og.dx_h[:, rows, :]
+            sg.lat, sg.heightmap = og.lat[rows], og.heightmap[rows]
+        s = synth(name, H, W, L, geom=og)
+        st = (s["p"][rows], s["u"][:, rows], s["v"][:, rows], s["t"][:, rows], s["q"][:, rows])
+        gt = np.full(st[0].shape, 288.0)
+        del s
+        cells = st[1].size
         t0 = time.perf_counter()
-        nst = 12
-        for _ in range(nst):
-            st = dynamics.matsuno_timestep(*st, dt, og)
+        for n in range(nst):
+            st = dynamics.matsuno_timestep(*st, dt, sg)
+            if phys:
+                t_n, gt = physics.solar_timestep(st[3], st[0], gt, dt, PHYS_UTC0 + n * dt, sg)
+                st = (st[0], st[1], st[2], t_n, st[4])
         el = time.perf_counter() - t0
-        return {"value": h * w * L * nst / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
-                "sample": "%d steps of a 360x180x%d grid (same recipe, fewer columns) with the NumPy "
-                          "oracle, %.1f s; host has %d cores" % (nst, L, el, os.cpu_count())}
+        return {"value": cells * nst / el, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+                "sample": "%s with the NumPy oracle%s, %.1f s; host has %d cores"
+                          % (what, " (dynamics + solar_timestep)" if phys else "", el, os.cpu_count())}
     s = synth(name, H, W)
     t0 = time.perf_counter()
     if name == "c2":
@@ -156,8 +189,28 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
         runner = BandRunner(eng, rank, world, cx.ring if world > 1 else dist)
         region = {}
 
+        phys = "phys" in name
+        if phys:
+            core.set_ground(np.full((nrows, W), 288.0))
+        clock = [0]
+
         def run_chunk(n, timed):
-            if world == 1:
+            if phys:
+                # configs[4]: dynamics step + solar_timestep, both asynchronous on the handle's stream
+                if world > 1:
+                    raise SystemExit("bench.py: c5_phys is a 1-GPU workload here")
+                ev = None
+                if timed:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                for _ in range(n):
+                    core.step(1, dt)
+                    core.solar_step(geom, dt, PHYS_UTC0 + clock[0] * dt)
+                    clock[0] += 1
+                if timed:
+                    ev[1].record()
+                    region.setdefault("events", []).append(ev)
+            elif world == 1:
                 if timed:   # same launches, bracketed by HIP events on the launch stream
                     region["ms"] = region.get("ms", 0.0) + core.time_steps(n, dt, per_kernel=False)[0]
                 else:
@@ -210,6 +263,7 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
         tt = torch.tensor([per], dtype=torch.float64, device="cuda" if cx.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         per = float(tt.item())
+    n_settle = 0
     if active:
         n_settle = min(20000, int(SETTLE_S / max(per, 1e-6))) // k * k
         run(n_settle)
@@ -217,22 +271,34 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
             core.restore()
             since[0] = 0
     run(warmup)
-    fence()
-    t0 = time.perf_counter()
-    run(steps, timed=True)
-    t_queued = time.perf_counter() - t0               # the host has queued all K steps
-    fence()
-    el = time.perf_counter() - t0
-    if dist is not None and not solo:
-        tt = torch.tensor([el], dtype=torch.float64, device="cuda" if cx.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+    # The timed region: a block of exactly `steps` steps between two fences (barrier + synchronize),
+    # repeated until MIN_TIMED_S seconds have been timed (every rank sees the same all-reduced block
+    # times, so all stop together); the median block is the result.
+    blocks, t_queued = [], 0.0
+    while True:
+        fence()
+        t0 = time.perf_counter()
+        run(steps, timed=True)
+        t_queued += time.perf_counter() - t0          # the host has queued all K steps
+        fence()
+        el = time.perf_counter() - t0
+        if dist is not None and not solo:
+            tt = torch.tensor([el], dtype=torch.float64, device="cuda" if cx.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        blocks.append(el)
+        if sum(blocks) >= MIN_TIMED_S or len(blocks) >= MAX_BLOCKS:
+            break
+    el = float(np.median(blocks))
+    t_queued /= len(blocks)
     if active:
         assert core.diag(_lib.DIAG_ANY_NAN) == 0.0, "state went NaN during the timed run"
         cells = H * W * L
         value = cells * steps / el
         res = {"workload": desc, "grid": [W, H] + ([L] if L > 1 else []), "n_gpus": world, "steps": steps,
                "warmup": warmup, "value": value, "ms_per_step": el / steps * 1e3,
+               "ms_per_step_min": min(blocks) / steps * 1e3, "ms_per_step_max": max(blocks) / steps * 1e3,
+               "timed_blocks": len(blocks), "timed_seconds": sum(blocks), "settle_steps": 2 * k + n_settle,
                "dtype": "f32" if name.endswith("_f32") else "f64",
                "bytes_per_cell_update": bpc,
                "hbm_roofline_frac_whole_job": value * bpc / (world * HBM_PEAK_GBS * 1e9),
@@ -263,28 +329,44 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
             # back-to-back launches leave no gap (rocprofv3 trace: next start == previous end).
             # "kernel_ms_isolated" is a second pass with an event pair around every launch
             # (idle gaps between launches let the chip clock higher, so it reads lower).
-            _, kiso = core.time_steps(min(steps, 50), dt)
+            if "events" in region:                     # c5_phys: torch events around every block
+                region["ms"] = sum(e0.elapsed_time(e1) for e0, e1 in region["events"])
+            launches_timed = steps * len(blocks)
+            kiso = None
             launches = 1
             if model == "PE25D":
-                # pe_update_kernel runs once per Euler stage: half of the step's algorithmic bytes
-                kname, kms, launches = "pe_update_kernel", kiso, 2
+                # one Euler stage = five launches (spu filter, pit, geopot, pgf filter, update) on two
+                # streams; the roofline entry is the WHOLE stage: half of the step's algorithmic bytes over
+                # half of the step's device time (HIP events around the timed blocks)
+                kname, kms, launches = ("pe25d stage: pe_spu_filter + pe_pit + pe_geopot + pe_pgf_filter + pe_update_rows"
+                                        + (" (+ half of pe_radiation)" if phys else "")), region["ms"] / launches_timed / 2, 2
             elif variant == "fused" and model == "SW2D":
                 # plain shallow water steps in pairs (one launch = two steps): per-step figures
-                kname, kms = "sw2d_fused2_kernel (two steps per launch; per step)", region["ms"] / steps
+                kname, kms = "sw2d_fused2_kernel (two steps per launch; per step)", region["ms"] / launches_timed
+                _, kiso = core.time_steps(min(steps, 50), dt)
             elif variant == "fused":
-                kname, kms = "sw2d_fused_kernel", region["ms"] / steps
+                kname, kms = "sw2d_fused_kernel", region["ms"] / launches_timed
+                _, kiso = core.time_steps(min(steps, 50), dt)
             else:
+                _, kiso = core.time_steps(min(steps, 50), dt)
                 kname, kms = "sw2d_stage_kernel (corrector stage)", kiso
             ach = cells * bpc / launches / (kms * 1e-3) / 1e9
             # HBM bytes per launch from the rocprofv3 PMC passes of this same command (separate
-            # FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied): profiles/r01/traffic.json,
+            # FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied): profiles/<round>/traffic.json,
             # written by tools_prof.sh + tools_traffic.py; null if that file is absent
             traffic = None
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
-                traffic = tj[name][("gcm::" + kname.split(" ")[0])]["hbm_bytes_per_launch"]   # fp64 runs only
-                if "two steps per launch" in kname:
-                    traffic /= 2.0                          # per step, as kernel_ms
+                tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic.json")))[name]
+                if model == "PE25D":                   # sum over the stage's kernels (each once per stage)
+                    traffic = sum(v["hbm_bytes_per_launch"] for kk, v in tj.items()
+                                  if kk.startswith("gcm::pe_") and "to_device" not in kk and "to_host" not in kk
+                                  and "radiation" not in kk and "energy" not in kk)
+                    if phys:
+                        traffic += tj["gcm::pe_radiation_kernel"]["hbm_bytes_per_launch"] / 2.0
+                else:
+                    traffic = tj[("gcm::" + kname.split(" ")[0])]["hbm_bytes_per_launch"]   # fp64 runs only
+                    if "two steps per launch" in kname:
+                        traffic /= 2.0                      # per step, as kernel_ms
             except Exception:
                 pass
             # context: what a plain device-to-device copy of the same bytes (state in, state out)
@@ -307,7 +389,7 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
                                              (traffic or cells * bpc / launches) / (kms * 1e-3) / 1e9 / copy_gbs}
             res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
-                               "kernel_ms": kms, "kernel_ms_isolated": kiso,
+                               "kernel_ms": kms, "kernel_ms_isolated": kiso, "launches_timed": launches_timed * launches,
                                "algorithmic_bytes_per_launch": cells * bpc / launches}
         core.close()
     if dist is not None:
@@ -412,7 +494,10 @@ def main():
         out = {
             "metric": "cell-updates/s (C-grid Matsuno step)", "value": main_res["value"],
             "unit": "cell-updates/s", "n_gpus": cx.world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": main_res["ms_per_step"], "ms_per_step_min": main_res["ms_per_step_min"],
+            "ms_per_step_max": main_res["ms_per_step_max"], "timed_blocks": main_res["timed_blocks"],
+            "timed_seconds": main_res["timed_seconds"], "settle_steps": main_res["settle_steps"],
+            "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": main_res["dtype"], "data": "synthetic",
             "config": {"workload": main_res["workload"], "grid": main_res["grid"], "variant": a.variant,
                        "decomposition": main_res["decomposition"],

@@ -996,22 +996,32 @@ struct RadArgsT {
     const double *tlw, *tsw, *csw_top, *clw_b_div, *swfac;   // [L] level tables (host-built)
     const double *coslat, *sinlat, *lon;                     // [Hg], [Hg], [W]
     double *gt;                                              // ground temperature [H][W]
-    T *emis, *lwb, *ttp;                                     // 3-D scratch (parked per level)
-    T *dTdt, *dtg;                                           // tendencies out (3-D, 2-D scratch)
+    T *dTdt, *dtg;                                           // tendencies out of the diagnostic form (3-D, 2-D scratch)
     double hour_angle, albedo, dt;
     int apply;                                               // 1: t, gt updated in place
 };
 
 // The arithmetic is float64 for either storage type T: the column physics is a small share of a
 // step, and the fp32 variant then differs from fp64 only by the rounding of what it stores.
-template <typename T>
-__global__ __launch_bounds__(256) void pe_radiation_kernel(PeArgsT<T> a, RadArgsT<T> r, T *t_inout) {
+// One thread per column.  The long-wave absorption needs the upwelling flux from BELOW a level and
+// the downwelling flux from ABOVE it, two opposite scans: the bottom-up scan parks one value per
+// level (the absorbed upwelling) and the top-down scan recomputes the level's emission from theta,
+// which it reads a second time (the first read is a few tens of KB back: it comes from the caches).
+// LMAX > 0: L <= LMAX and the parked column lives in registers (loops unrolled); LMAX == 0: any L,
+// parked in LDS, park[L][threads].  The kernel reads theta and writes it (apply) or dTdt (diagnostic);
+// nothing else goes through HBM.
+constexpr int kRadThreads = 128;
+template <typename T, int LMAX>
+__global__ __launch_bounds__(kRadThreads) void pe_radiation_kernel(PeArgsT<T> a, RadArgsT<T> r, T *t_inout) {
     __shared__ double tab[kExnerTabDoubles];
-    tab[threadIdx.x] = a.exner_tab[threadIdx.x];
+    extern __shared__ unsigned char rad_park_raw[];
+    for (int n = threadIdx.x; n < kExnerTabDoubles; n += kRadThreads) tab[n] = a.exner_tab[n];
     __syncthreads();
     constexpr double kSolar = 1.3608 * 1000.0, kSb = 5.67e-8, kCg = 1.13e6;   // constants.py:59,71,25
     const int W = a.W, L = a.L;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    double *p_lwb = (double *)rad_park_raw + threadIdx.x;
+    double lwb_reg[LMAX > 0 ? LMAX : 1];
+    const int i = blockIdx.x * kRadThreads + threadIdx.x;
     const int j = blockIdx.y;
     if (i >= W) return;
     const int jg = wrapi(a.row0 + j, a.Hg);
@@ -1024,36 +1034,49 @@ __global__ __launch_bounds__(256) void pe_radiation_kernel(PeArgsT<T> a, RadArgs
     const double S = (1 - r.albedo) * Sc * r.csw_top[0];
     const double g2 = gt * gt;
     const double U_s = 1 * kSb * (g2 * g2);
-    double B = 0.0, up = 0.0;
-    for (int k = 0; k < L; ++k) {                            // bottom-up: emission, B, LWA_b
-        const long o = c3 + (long)k * W;
+    // true temperature and emission of one level (to_true_temp; grey_solar.py emission)
+    const auto emission = [&](int k, double *tt_out) {
         const double tp = pc * (double)a.sig[k] + ptop;
-        const double tt = (double)t_inout[o] * exner(tp, tab);       // to_true_temp
+        const double tt = (double)t_inout[c3 + (long)k * W] * exner(tp, tab);
         const double t2 = tt * tt;
-        const double em = (1 - r.tlw[k]) * kSb * (t2 * t2);
+        *tt_out = tt;
+        return (1 - r.tlw[k]) * kSb * (t2 * t2);
+    };
+    double B = 0.0, up = 0.0;
+#pragma unroll(LMAX > 0 ? LMAX : 2)
+    for (int k = 0; k < (LMAX > 0 ? LMAX : L); ++k) {       // bottom-up: emission, B, LWA_b
+        if (LMAX > 0 && k >= L) break;
+        double tt;
+        const double em = emission(k, &tt);
         B += em * r.clw_b_div[k];
-        r.lwb[o] = (T)(up * (1 - r.tlw[k]));
+        const double lwb = up * (1 - r.tlw[k]);
+        if (LMAX > 0) lwb_reg[k] = lwb;
+        else p_lwb[k * kRadThreads] = lwb;
         up = up * r.tlw[k] + em;
-        r.emis[o] = (T)em;
-        r.ttp[o] = (T)tt;
     }
     const double dtg = (B + S - U_s) / kCg / (.1);
-    r.dtg[c2] = (T)dtg;
     if (r.apply) r.gt[c2] = gt + dtg * r.dt;
+    else r.dtg[c2] = (T)dtg;
     double down = 0.0;
-    for (int k = L - 1; k >= 0; --k) {                       // top-down: LWA_a, then eq. 2.34
+#pragma unroll(LMAX > 0 ? LMAX : 2)
+    for (int kk = 0; kk < (LMAX > 0 ? LMAX : L); ++kk) {     // top-down: LWA_a, then eq. 2.34
+        const int k = (LMAX > 0 ? LMAX : L) - 1 - kk;
+        if (LMAX > 0 && k >= L) continue;
         const long o = c3 + (long)k * W;
-        const double em = (double)r.emis[o];
+        double tt;
+        const double em = emission(k, &tt);
         const double lwa = down * (1 - r.tlw[k]);
         down = down * r.tlw[k] + em;
         const double U_n = r.clw_b_div[k] * U_s * (1 - r.tlw[k]);
         const double S_n = r.swfac[k] * Sc;
-        const double dTdt = (U_n + S_n - 2 * em + lwa + (double)r.lwb[o]) * (kG / (kCp * pc * (double)a.dsig[k]));
-        r.dTdt[o] = (T)dTdt;
+        const double lwb = LMAX > 0 ? lwb_reg[k] : p_lwb[k * kRadThreads];
+        const double dTdt = (U_n + S_n - 2 * em + lwa + lwb) * (kG / (kCp * pc * (double)a.dsig[k]));
         if (r.apply) {
             const double tp = pc * (double)a.sig[k] + ptop;
-            const double tt_n = (double)r.ttp[o] + dTdt * r.dt;
+            const double tt_n = tt + dTdt * r.dt;
             t_inout[o] = (T)(tt_n * rcp(exner(tp, tab)));          // to_potential_temp
+        } else {
+            r.dTdt[o] = (T)dTdt;
         }
     }
 }
@@ -1090,7 +1113,6 @@ struct PeBufs {
     // state sets: 0/1 ping-pong (cur = set[cur_i]), 2 = star.  [f] p,u,v,t,q; interior pointers
     T *st[3][GCM_NFIELDS] = {};
     T *spu = nullptr, *phi = nullptr, *pgfu = nullptr, *pit = nullptr, *pn = nullptr;
-    T *rad_scr = nullptr;                       // 3-D scratch of the radiation kernel, allocated on first use
     T *part = nullptr;                          // (kMaxSeg - 1) slabs like pit
     T *cor_u = nullptr, *cor_v = nullptr;
     T *inv_dxj = nullptr, *inv_dxh = nullptr, *sig = nullptr, *dsig = nullptr, *inv_dsig = nullptr,
@@ -1266,6 +1288,8 @@ static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
                             (int)filter_lds_bytes<T>(m)) != hipSuccess ||
         hipFuncSetAttribute((const void *)pe_geopot_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(L * kColThreads * sizeof(T))) != hipSuccess ||
+        hipFuncSetAttribute((const void *)pe_radiation_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(double) * (size_t)L * kRadThreads)) != hipSuccess ||
         hipFuncSetAttribute((const void *)pe_update_rows_kernel<T, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)upd_lds_bytes<T>(7, L)) != hipSuccess ||
         hipFuncSetAttribute((const void *)pe_update_rows_kernel<T, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1386,8 +1410,10 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
         pe25d_destroy(m);
         return nullptr;
     }
-    if ((size_t)L * kColThreads * sizeof(double) + kExnerTabDoubles * sizeof(double) > 160 * 1024) {
-        *err = "GCM_PE25D: too many layers for the column kernel's LDS (max 158)";
+    if ((size_t)L * kColThreads * sizeof(double) + kExnerTabDoubles * sizeof(double) > 160 * 1024 ||
+        sizeof(double) * (size_t)L * kRadThreads + 4096 > 160 * 1024 ||
+        upd_lds_bytes<double>(3, L) + 4096 > 160 * 1024) {
+        *err = "GCM_PE25D: too many layers for the column kernels' LDS (max 100)";
         pe25d_destroy(m);
         return nullptr;
     }
@@ -1835,15 +1861,17 @@ static int radiation_launch(Pe25d *m, bool apply, double dt, double hour_angle, 
     r.tlw = m->rad_tab; r.tsw = r.tlw + L; r.csw_top = r.tsw + L; r.clw_b_div = r.csw_top + L; r.swfac = r.clw_b_div + L;
     r.coslat = m->rad_geo; r.sinlat = m->rad_geo + Hg; r.lon = m->rad_geo + 2 * Hg;
     r.gt = m->gt;
-    if (!B.rad_scr) {
-        T *d = nullptr;
-        if (!dev_upload<T>(m, &d, nullptr, (size_t)H * W * L)) { *err = "hip: radiation scratch allocation failed"; return GCM_ERR_HIP; }
-        B.rad_scr = d;
-    }
-    r.emis = B.spu; r.lwb = B.phi; r.ttp = B.rad_scr; r.dTdt = B.pgfu; r.dtg = B.pit;
+    r.dTdt = B.pgfu; r.dtg = B.pit;
     r.hour_angle = hour_angle;
     r.albedo = albedo; r.dt = dt; r.apply = apply ? 1 : 0;
-    hipLaunchKernelGGL(pe_radiation_kernel<T>, dim3((W + 255) / 256, H), dim3(256), 0, s, a, r, B.st[m->cur_i][GCM_T]);
+    {
+        const dim3 gg((W + kRadThreads - 1) / kRadThreads, H);
+        T *th = B.st[m->cur_i][GCM_T];
+        static const bool generic = getenv("GCM_PE_RAD_GENERIC") != nullptr;     // diagnostic: the LDS-parked form
+        if (L <= 24 && !generic) hipLaunchKernelGGL((pe_radiation_kernel<T, 24>), gg, dim3(kRadThreads), 0, s, a, r, th);
+        else if (L <= 40 && !generic) hipLaunchKernelGGL((pe_radiation_kernel<T, 40>), gg, dim3(kRadThreads), 0, s, a, r, th);
+        else hipLaunchKernelGGL((pe_radiation_kernel<T, 0>), gg, dim3(kRadThreads), sizeof(double) * (size_t)L * kRadThreads, s, a, r, th);
+    }
     if (hipGetLastError() != hipSuccess) { *err = "hip: radiation kernel launch failed"; return GCM_ERR_HIP; }
     // solar_timestep (apply) stays asynchronous on `s`; the diagnostics form copies its results back
     if (dtg_host) {
