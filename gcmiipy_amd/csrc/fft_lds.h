@@ -255,14 +255,19 @@ __device__ __forceinline__ void dft_composite(V (&v)[R1 * R2], const V *tw, int 
     }
 }
 
-// one Stockham pass, one butterfly per thread.  src(i) -> V reads element i of the pass input,
-// dst(i, V) writes element i of its output; `fence` = both are the same LDS buffer.
+// one Stockham pass, one butterfly per thread.  src(i, m) -> V reads element i of the pass input
+// (m = its position in this thread's butterfly), dst(i, V) writes element i of its output; `fence` =
+// both are the same LDS buffer.  wpre, if given, is this thread's base twiddle of the pass
+// (tw[k N / (Ns R)], forward sign), fetched once by the caller instead of once per call.
 template <int R1, int R2, bool INV, typename V, typename Src, typename Dst>
 __device__ __forceinline__ void composite_pass(const Src &src, const Dst &dst, bool fence, const V *tw, int N, int Ns,
-                                               unsigned magic) {
+                                               unsigned magic, const V *wpre = nullptr, int tid = -1) {
     constexpr int R = R1 * R2;
     const int nb = N / R;
-    const int b = threadIdx.x;
+    // tid: the thread index as the caller holds it.  A caller that runs the passes inside a loop hands
+    // in a copy it has made opaque to the optimiser, so that the index arithmetic of all passes is not
+    // hoisted out of that loop (it would be held in hundreds of registers).
+    const int b = tid >= 0 ? tid : (int)threadIdx.x;
     const bool act = b < nb;
     V v[R];
     int j0 = 0;
@@ -271,13 +276,18 @@ __device__ __forceinline__ void composite_pass(const Src &src, const Dst &dst, b
         const int k = b - blk * Ns;
         j0 = blk * Ns * R + k;
 #pragma unroll
-        for (int m = 0; m < R; ++m) v[m] = src(b + m * nb);
+        for (int m = 0; m < R; ++m) v[m] = src(b + m * nb, m);
         if (Ns > 1) {
             // pass twiddles w^(m t1): ONE gathered table entry per butterfly (the lanes' indices are
             // strided, so a gather costs a cache line per lane), the powers by squaring / one product
             const int t1 = k * (nb / Ns);          // k * N / (Ns R)
             V wp[R];
-            wp[1] = twid<INV>(tw, t1);
+            if (wpre) {
+                wp[1] = *wpre;
+                if (INV) wp[1].y = -wp[1].y;
+            } else {
+                wp[1] = twid<INV>(tw, t1);
+            }
 #pragma unroll
             for (int m = 2; m < R; ++m) wp[m] = (m % 2 == 0) ? cmul(wp[m / 2], wp[m / 2]) : cmul(wp[m - 1], wp[1]);
 #pragma unroll
@@ -305,11 +315,11 @@ constexpr unsigned pass_bit(int a, int b) {
 
 template <int MAXR, unsigned MASK, bool INV, typename V, typename Src, typename Dst>
 __device__ __forceinline__ void pass_dispatch(int r1, int r2, const Src &src, const Dst &dst, bool fence, const V *tw,
-                                              int N, int Ns, unsigned magic) {
+                                              int N, int Ns, unsigned magic, const V *wpre = nullptr, int tid = -1) {
 #define GCM_PASS(A, B)                                                                      \
     case (A) * 8 + (B):                                                                     \
         if constexpr ((A) * (B) <= MAXR && (MASK == 0 || (MASK & pass_bit(A, B)) != 0))     \
-            composite_pass<A, B, INV>(src, dst, fence, tw, N, Ns, magic);                   \
+            composite_pass<A, B, INV>(src, dst, fence, tw, N, Ns, magic, wpre, tid);        \
         break;
     switch (r1 * 8 + r2) {
         GCM_PASS(2, 1) GCM_PASS(3, 1) GCM_PASS(4, 1) GCM_PASS(5, 1)
@@ -328,9 +338,9 @@ __device__ __forceinline__ void filter_rows_composite(typename Vec2<T>::type *x,
                                                       const T *S, bool load_reads_x = false) {
     using V = typename Vec2<T>::type;
     const T inv_n = T(1.0) / (T)N;
-    const auto lds_src = [x](int i) { return x[i]; };
+    const auto lds_src = [x](int i, int) { return x[i]; };
     const auto lds_dst = [x](int i, V v) { x[i] = v; };
-    const auto lds_src_filtered = [x, S, N, inv_n](int i) {
+    const auto lds_src_filtered = [x, S, N, inv_n](int i, int) {
         const T s = S[i <= N / 2 ? i : N - i] * inv_n;
         const V v = x[i];
         return mkv<V>(v.x * s, v.y * s);
@@ -355,6 +365,76 @@ __device__ __forceinline__ void filter_rows_composite(typename Vec2<T>::type *x,
         Ns *= P.r1[pass] * P.r2[pass];
     }
     pass_dispatch<MAXR, MASK, true>(P.r1[np - 1], P.r2[np - 1], lds_src, store, false, tw, N, Ns, P.magic[np - 1]);
+}
+
+// The same filter for a workgroup that loops over several row pairs of ONE latitude (the filter
+// multiplier and the pass twiddles depend on the thread and the latitude only): what the passes
+// fetch from tables is fetched once, before the loop, into FilterConsts, and the first forward pass
+// takes its inputs from registers (`first(i, m)`: the m-th input of this thread's butterfly, element
+// i = threadIdx.x + m N / R0), so that a caller can request the next pair's inputs while this pair is
+// transformed.  The multiplier row (already divided by N) is read from LDS.  Plans of up to four passes.
+template <typename T>
+struct FilterConsts {
+    typename Vec2<T>::type w[3];   // base twiddle of passes 1..3 (forward sign)
+    const T *s;                    // LDS: S[n] / N, n = 0 .. N/2 (the caller fills it)
+};
+template <typename T>
+__device__ __forceinline__ void filter_consts(FilterConsts<T> &c, const typename Vec2<T>::type *tw, const SuperPlan &P, int N) {
+    using V = typename Vec2<T>::type;
+    const int b = threadIdx.x;
+    int Ns = P.r1[0] * P.r2[0];
+#pragma unroll
+    for (int pass = 1; pass < 4; ++pass) {
+        c.w[pass - 1] = mkv<V>(T(1.0), T(0.0));
+        if (pass < P.npass) {
+            const int R = P.r1[pass] * P.r2[pass], nb = N / R;
+            const int bb = min(b, nb - 1);
+            const int blk = (int)__umulhi((unsigned)bb, P.magic[pass]);
+            const int k = bb - blk * Ns;
+            c.w[pass - 1] = tw[k * (nb / Ns)];
+            Ns *= R;
+        }
+    }
+}
+// after_first() runs when the first forward pass has consumed its inputs: the caller re-uses their
+// registers for the next request there.
+template <int MAXR, unsigned MASK, typename T, typename First, typename After, typename Store>
+__device__ __forceinline__ void filter_rows_hoisted(typename Vec2<T>::type *x, const First &first, const After &after_first,
+                                                    const Store &store, const typename Vec2<T>::type *tw, const SuperPlan &P,
+                                                    int N, const FilterConsts<T> &c, int tid) {
+    using V = typename Vec2<T>::type;
+    const auto reg_src = [&first](int i, int m) { return first(i, m); };
+    const auto lds_src = [x](int i, int) { return x[i]; };
+    const auto lds_dst = [x](int i, V v) { x[i] = v; };
+    const T *sl = c.s;
+    const auto lds_src_filtered = [x, sl, N](int i, int) {
+        const T sv = sl[i <= N / 2 ? i : N - i];
+        const V v = x[i];
+        return mkv<V>(v.x * sv, v.y * sv);
+    };
+    const int np = P.npass;
+    const int R0 = P.r1[0] * P.r2[0];
+    // forward: pass 0 from registers, then up to three LDS passes
+    pass_dispatch<MAXR, MASK, false>(P.r1[0], P.r2[0], reg_src, lds_dst, false, tw, N, 1, P.magic[0], (const V *)nullptr, tid);
+    after_first();
+    int Ns = R0;
+    if (np > 1) { pass_dispatch<MAXR, MASK, false>(P.r1[1], P.r2[1], lds_src, lds_dst, true, tw, N, Ns, P.magic[1], &c.w[0], tid); Ns *= P.r1[1] * P.r2[1]; }
+    if (np > 2) { pass_dispatch<MAXR, MASK, false>(P.r1[2], P.r2[2], lds_src, lds_dst, true, tw, N, Ns, P.magic[2], &c.w[1], tid); Ns *= P.r1[2] * P.r2[2]; }
+    if (np > 3) { pass_dispatch<MAXR, MASK, false>(P.r1[3], P.r2[3], lds_src, lds_dst, true, tw, N, Ns, P.magic[3], &c.w[2], tid); }
+    // inverse: pass 0 applies the multiplier; the last pass stores
+    if (np == 1) {
+        pass_dispatch<MAXR, MASK, true>(P.r1[0], P.r2[0], lds_src_filtered, store, false, tw, N, 1, P.magic[0], (const V *)nullptr, tid);
+        return;
+    }
+    pass_dispatch<MAXR, MASK, true>(P.r1[0], P.r2[0], lds_src_filtered, lds_dst, true, tw, N, 1, P.magic[0], (const V *)nullptr, tid);
+    Ns = R0;
+    if (np == 2) { pass_dispatch<MAXR, MASK, true>(P.r1[1], P.r2[1], lds_src, store, false, tw, N, Ns, P.magic[1], &c.w[0], tid); return; }
+    pass_dispatch<MAXR, MASK, true>(P.r1[1], P.r2[1], lds_src, lds_dst, true, tw, N, Ns, P.magic[1], &c.w[0], tid);
+    Ns *= P.r1[1] * P.r2[1];
+    if (np == 3) { pass_dispatch<MAXR, MASK, true>(P.r1[2], P.r2[2], lds_src, store, false, tw, N, Ns, P.magic[2], &c.w[1], tid); return; }
+    pass_dispatch<MAXR, MASK, true>(P.r1[2], P.r2[2], lds_src, lds_dst, true, tw, N, Ns, P.magic[2], &c.w[1], tid);
+    Ns *= P.r1[2] * P.r2[2];
+    pass_dispatch<MAXR, MASK, true>(P.r1[3], P.r2[3], lds_src, store, false, tw, N, Ns, P.magic[3], &c.w[2], tid);
 }
 
 // generic path: filter two real rows held as re/im of x[0..N): FFT, multiply by S[n] (n folded),

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(512) void pe_spu_filter_kernel(PeArgsT<T> a) {
     const T *su0 = a.su + ix.r3(j) + (long)k0 * W;
     const T *su1 = su0 + W;
     T *o0 = a.spu + ix.r3(j) + (long)k0 * W;
-    const auto load = [=](int i) {
+    const auto load = [=](int i, int = 0) {
         const int ie = i + 1 == W ? 0 : i + 1;
         const T pe = (sp[i] + sp[ie]) * T(0.5);      // iph(p), dynamics.py:15-17
         return mkv<V>(su0[i] * pe, two ? su1[i] * pe : T(0.0));
@@ -116,6 +116,81 @@ __global__ __launch_bounds__(512) void pe_spu_filter_kernel(PeArgsT<T> a) {
         }
     } else {
         for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, load(i));
+    }
+}
+
+// K1, looping form: the workgroup of (row, group of level pairs) filters its pairs one after the
+// other.  What the passes fetch from tables (their twiddles, the filter multiplier) and iph(sp) depend
+// on the thread and the row only and are fetched once; the su values of the NEXT pair are requested
+// before the current pair is transformed (two register sets that swap by name), so the only waits
+// left inside the loop are LDS round trips and barriers.
+// NIN: radix of the plan's first pass (inputs per thread) where the instantiation knows it, else MAXR
+template <typename T, int MAXR, unsigned MASK = 0, int NIN = MAXR>
+__global__ __launch_bounds__(512) void pe_spu_filter_loop_kernel(PeArgsT<T> a, int pairs_per_wg) {
+    using V = typename Vec2<T>::type;
+    extern __shared__ unsigned char lds_raw[];
+    V *x = (V *)lds_raw;
+    const Idx ix{a.W, a.H, a.L, a.wrap};
+    const int W = a.W, L = a.L;
+    const int j = a.j0 + blockIdx.x;
+    const int npairs = (L + 1) / 2;
+    const int pb0 = blockIdx.y * pairs_per_wg, pb1 = min(pb0 + pairs_per_wg, npairs);
+    if (pb0 >= pb1) return;                                      // uniform
+    const int jg = wrapi(a.row0 + j, a.Hg);
+    // LDS: the complex row, then iph(sp) of the row and the row's filter multiplier / W
+    T *pe = (T *)(x + W), *sl = pe + W;
+    {
+        const T *sp = a.sp + ix.r2(j), *S = a.smul + (long)jg * (W / 2 + 1);
+        const T inv_n = T(1.0) / (T)W;
+        for (int i = threadIdx.x; i < W; i += blockDim.x) {
+            const int ie = i + 1 == W ? 0 : i + 1;
+            pe[i] = (sp[i] + sp[ie]) * T(0.5);                   // dynamics.py:15-17
+            if (i <= W / 2) sl[i] = S[i] * inv_n;
+        }
+    }
+    FilterConsts<T> c;
+    filter_consts<T>(c, a.tw, a.cplan, W);
+    c.s = sl;
+    __syncthreads();
+    const int nb0 = W / (a.cplan.r1[0] * a.cplan.r2[0]);
+    const T *su_row = a.su + ix.r3(j);
+    T *out_row = a.spu + ix.r3(j);
+    V in[NIN];
+    // unconditional requests (an odd L's last pair reads its single level twice; the copy is not stored)
+    const auto request = [&](int pair, int tid) {
+        const int k0 = 2 * pair;
+        const T *s0 = su_row + (long)k0 * W, *s1 = s0 + (k0 + 1 < L ? W : 0);
+#pragma unroll
+        for (int m = 0; m < NIN; ++m) {
+            const int i = min(tid + m * nb0, W - 1);
+            in[m] = mkv<V>(s0[i], s1[i]);
+        }
+    };
+    request(pb0, threadIdx.x);
+    for (int pair = pb0; pair < pb1; ++pair) {
+        const int k0 = 2 * pair;
+        const bool two = k0 + 1 < L;
+        T *o0 = out_row + (long)k0 * W;
+        // The thread index and the base twiddles are made opaque per iteration: otherwise the index
+        // arithmetic of all passes and every power of the twiddles (loop invariants now) would be
+        // hoisted out of the loop and held in hundreds of registers.
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        FilterConsts<T> cc = c;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) asm volatile("" : "+v"(cc.w[n].x), "+v"(cc.w[n].y));
+        const auto first = [&](int i, int m) {
+            const T p = pe[i];
+            return mkv<V>(in[m < NIN ? m : 0].x * p, in[m < NIN ? m : 0].y * p);
+        };
+        // the next pair's su goes into the same registers as soon as the first pass has read them,
+        // and is in flight during the other passes
+        const auto after_first = [&]() { request(min(pair + 1, pb1 - 1), tid); };
+        const auto store = [=](int i, V v) {
+            o0[i] = v.x;
+            if (two) o0[W + i] = v.y;
+        };
+        filter_rows_hoisted<MAXR, MASK, T>(x, first, after_first, store, a.tw, a.cplan, W, cc, tid);
     }
 }
 
@@ -385,7 +460,7 @@ __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
         }
         __syncthreads();
         if (MAXR > 0) {
-            const auto from_x = [x](int i) { return x[i]; };
+            const auto from_x = [x](int i, int) { return x[i]; };
             filter_rows_composite<MAXR, MASK, T>(x, from_x, store, a.tw, a.cplan, W, a.smul + (long)jg * (W / 2 + 1), true);
         } else {
             const V *res = filter_rows<T>(x, x + W, a.tw, a.plan, a.smul + (long)jg * (W / 2 + 1));
@@ -1132,6 +1207,7 @@ struct Pe25d {
     bool star_valid = false;
     int nseg = 1;                               // level segments of K4, chosen from the band's size
     int upd_rows = 7;                           // rows per workgroup of the row-group K4 (0: one-wave form)
+    int cus = 256;
     int pack_set = -1;                          // >= 0: state set gcm_halo_pack reads (step_phase)
     double *stage3 = nullptr;                   // float64 transpose staging, host layout
     double *exner_tab = nullptr;
@@ -1199,6 +1275,20 @@ static FilterKernel<T> spu_filter_kernel_for(const SuperPlan &P) {
     if (P.maxr <= 16) return pe_spu_filter_kernel<T, 16>;
     return pe_spu_filter_kernel<T, 25>;
 }
+template <typename T> using FilterLoopKernel = void (*)(PeArgsT<T>, int);
+template <typename T>
+static FilterLoopKernel<T> spu_filter_loop_kernel_for(const SuperPlan &P) {
+    if (!P.ok || P.npass > 4) return nullptr;
+    // the plans these masks stand for start with a pass of radix 5.2 / 5.3 / 4.4 (make_super_plan)
+    if (P.mask == kMask1440 && P.r1[0] * P.r2[0] == 10) return pe_spu_filter_loop_kernel<T, 12, kMask1440, 10>;
+    if (P.mask == kMask2880 && P.r1[0] * P.r2[0] == 15) return pe_spu_filter_loop_kernel<T, 16, kMask2880, 15>;
+    if (P.mask == kMask1440) return pe_spu_filter_loop_kernel<T, 12, kMask1440>;
+    if (P.mask == kMask2880) return pe_spu_filter_loop_kernel<T, 16, kMask2880>;
+    if (P.mask == kMask4096) return pe_spu_filter_loop_kernel<T, 16, kMask4096>;
+    if (P.maxr <= 12) return pe_spu_filter_loop_kernel<T, 12>;
+    if (P.maxr <= 16) return pe_spu_filter_loop_kernel<T, 16>;
+    return pe_spu_filter_loop_kernel<T, 25>;
+}
 template <typename T>
 static FilterKernel<T> pgf_filter_kernel_for(const SuperPlan &P) {
     if (!P.ok) return pe_pgf_filter_kernel<T, 0>;
@@ -1211,6 +1301,11 @@ static FilterKernel<T> pgf_filter_kernel_for(const SuperPlan &P) {
 }
 template <typename T>
 static size_t upd_lds_bytes(int R, int L) { return sizeof(T) * ((size_t)3 * (11 * R + 11) * 64 + 2 + 4 * (size_t)L); }
+// looping filter kernels: the complex row + iph(sp) of the row + the row's multiplier
+template <typename T>
+static size_t filter_loop_lds_bytes(const Pe25d *m) {
+    return (size_t)m->W * sizeof(typename Vec2<T>::type) + ((size_t)m->W + m->W / 2 + 1) * sizeof(T);
+}
 template <typename T>
 static size_t filter_lds_bytes(const Pe25d *m) {
     return (size_t)(m->cplan.ok ? 1 : 2) * m->W * sizeof(typename Vec2<T>::type);
@@ -1282,7 +1377,10 @@ static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
         }
         if (!dev_upload<T2>(m, &B.tw, tw.data(), W)) return "twiddles";
     }
-    if (hipFuncSetAttribute((const void *)spu_filter_kernel_for<T>(m->cplan), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if ((spu_filter_loop_kernel_for<T>(m->cplan) &&
+         hipFuncSetAttribute((const void *)spu_filter_loop_kernel_for<T>(m->cplan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)filter_loop_lds_bytes<T>(m)) != hipSuccess) ||
+        hipFuncSetAttribute((const void *)spu_filter_kernel_for<T>(m->cplan), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)filter_lds_bytes<T>(m)) != hipSuccess ||
         hipFuncSetAttribute((const void *)pgf_filter_kernel_for<T>(m->cplan), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)filter_lds_bytes<T>(m)) != hipSuccess ||
@@ -1425,6 +1523,7 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
         int dev = 0, cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        m->cus = cus;
         const long tiles = (long)((W + kUpdThreads - 1) / kUpdThreads) * m->H;
         long want = (5L * 8 * cus / 2 + tiles - 1) / tiles;
         if (const char *e = getenv("GCM_PE_LEVEL_SEGMENTS")) want = atoi(e);
@@ -1587,7 +1686,17 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
             else if (L <= 40) hipLaunchKernelGGL((pe_geopot_kernel<T, 40>), gg, dim3(kColThreads), 0, s2, a);
             else hipLaunchKernelGGL((pe_geopot_kernel<T, 0>), gg, dim3(kColThreads), sizeof(T) * (size_t)L * kColThreads, s2, a);
         }
-        hipLaunchKernelGGL(spu_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, s, a);
+        static const bool no_loop = getenv("GCM_PE_FILTER_NO_LOOP") != nullptr;        // diagnostic: one workgroup per pair
+        const FilterLoopKernel<T> k1 = (m->cfg.filter && W > 1 && !no_loop) ? spu_filter_loop_kernel_for<T>(m->cplan) : nullptr;
+        if (k1) {
+            // all pairs of a row in one workgroup when there are rows enough to fill the chip, else groups
+            const int rows = a.j1 - a.j0;
+            const int groups = std::min(pairs, std::max(1, (3 * m->cus + rows - 1) / rows));
+            const int ppw = (pairs + groups - 1) / groups;
+            hipLaunchKernelGGL(k1, dim3(rows, (pairs + ppw - 1) / ppw), dim3(fft_threads), filter_loop_lds_bytes<T>(m), s, a, ppw);
+        } else {
+            hipLaunchKernelGGL(spu_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, s, a);
+        }
         {
             const long tiles = (long)((W + 255) / 256) * (a.j1 - a.j0);
             hipLaunchKernelGGL(pe_pit_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, s, a);
