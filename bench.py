@@ -397,6 +397,65 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
     return res
 
 
+def bring_up_direct_rccl(cx, torch, dist):
+    """The ghost rows go over RCCL called directly (gcmiipy_amd.rccl; the library posts the exchange
+    itself, gcm_band_run).  Bringing that communicator up between devices cannot be rehearsed on the
+    one-GPU development box, so every step is agreed on by ALL ranks through torch.distributed
+    collectives issued from the main thread in the same order everywhere -- a rank that fails early
+    cannot leave the others parked in a different collective:
+      1. every rank loads librccl, rank 0 makes the unique id         -> all_reduce(MIN) of 'ok'
+      2. the id travels as a 128-byte CUDA tensor                      -> broadcast
+      3. ncclCommInitRank + a one-hop ring self-check on a watchdog thread (the only calls that can
+         hang), joined with a timeout                                  -> all_reduce(MIN) of 'ok'
+    Any failure: cx.exchange_fallback = <reason> (reported in the JSON line), torch.distributed
+    carries the exchange, and if a bring-up thread is still inside RCCL the process exits NON-ZERO
+    after printing (cx.stuck)."""
+    import threading
+
+    def agree(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item()) == 1
+
+    err, uid = None, None
+    try:
+        from gcmiipy_amd.rccl import RcclP2P
+        if cx.rank == 0:
+            uid = RcclP2P.new_unique_id()
+    except Exception as e:          # noqa: BLE001
+        err = "librccl / unique id: %r" % (e,)
+    if not agree(err is None):
+        cx.exchange_fallback = err or "librccl / unique id failed on another rank"
+        print("bench.py: direct RCCL exchange unavailable (%s); using torch.distributed" % cx.exchange_fallback, file=sys.stderr)
+        return
+    box_t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    if cx.rank == 0:
+        box_t.copy_(torch.frombuffer(bytearray(uid), dtype=torch.uint8))
+    dist.broadcast(box_t, src=0)
+    uid = bytes(box_t.cpu().numpy().tobytes())
+    box = {}
+
+    def init():
+        try:
+            torch.cuda.set_device(cx.local)           # the HIP device is per thread
+            ring = RcclP2P(None, cx.rank, cx.world, uid_bytes=uid)
+            ring.self_check()
+            box["ring"] = ring
+        except Exception as e:      # noqa: BLE001
+            box["err"] = e
+
+    th = threading.Thread(target=init, daemon=True)
+    th.start()
+    th.join(float(os.environ.get("GCM_BENCH_RCCL_TIMEOUT_S", "120")))
+    cx.stuck = th.is_alive()
+    if agree("ring" in box):
+        cx.ring, cx.exchange = box["ring"], "RCCL ncclSend/ncclRecv groups posted by the library (gcm_band_run)"
+        return
+    cx.exchange_fallback = ("ncclCommInitRank / self-check timed out" if cx.stuck
+                            else repr(box.get("err", "failed on another rank")))
+    print("bench.py: direct RCCL exchange unavailable (%s); using torch.distributed" % cx.exchange_fallback, file=sys.stderr)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -421,7 +480,7 @@ def main():
         cx.local = 0
     torch.cuda.set_device(cx.local)
     cx.dist = None
-    cx.ring, cx.exchange, cx.stuck = None, None, False
+    cx.ring, cx.exchange, cx.stuck, cx.exchange_fallback = None, None, False, None
     cx.backend = "nccl"
     if cx.world > 1:
         import torch.distributed as dist
@@ -438,34 +497,9 @@ def main():
         # library's comm stream, a few ctypes calls per exchange); torch.distributed bootstraps it and
         # does the barriers.  GCM_BENCH_EXCHANGE=torch keeps batch_isend_irecv.
         cx.ring, cx.exchange = dist, "torch.distributed batch_isend_irecv (%s)" % cx.backend
+        cx.exchange_fallback = None
         if cx.backend == "nccl" and os.environ.get("GCM_BENCH_EXCHANGE", "rccl") == "rccl":
-            # Bring the communicator up on a watchdog: ncclCommInitRank between devices cannot be
-            # rehearsed on the one-GPU development box, and a hang there must not take the whole run
-            # with it.  All ranks then agree (a torch.distributed reduction) on which path to use.
-            import threading
-            box = {}
-
-            def bring_up():
-                try:
-                    torch.cuda.set_device(cx.local)           # the HIP device is per thread
-                    from gcmiipy_amd.rccl import RcclP2P
-                    ring = RcclP2P(dist, cx.rank, cx.world)
-                    ring.self_check()
-                    box["ring"] = ring
-                except Exception as e:      # noqa: BLE001 -- any failure: the torch path still works
-                    box["err"] = e
-
-            th = threading.Thread(target=bring_up, daemon=True)
-            th.start()
-            th.join(float(os.environ.get("GCM_BENCH_RCCL_TIMEOUT_S", "120")))
-            ok = torch.tensor([1 if "ring" in box else 0], dtype=torch.int32, device="cuda")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 1:
-                cx.ring, cx.exchange = box["ring"], "RCCL ncclSend/ncclRecv groups (gcmiipy_amd.rccl)"
-            else:
-                cx.stuck = th.is_alive()
-                print("bench.py: direct RCCL exchange unavailable on some rank (%s); using torch.distributed"
-                      % box.get("err", "timed out" if th.is_alive() else "peer failed"), file=sys.stderr)
+            bring_up_direct_rccl(cx, torch, dist)
 
     main_res = run_workload(cx, a.workload, a.steps, a.warmup, a.variant)
     also = {}
@@ -506,6 +540,9 @@ def main():
         }
         if "roofline" in main_res:
             out["roofline"] = main_res["roofline"]
+        if cx.world > 1:
+            out["exchange"] = cx.exchange
+            out["exchange_fallback"] = cx.exchange_fallback     # null: the direct RCCL ring came up on every rank
         if "diagnostics" in main_res:
             out["diagnostics"] = main_res["diagnostics"]
         if "device_copy_same_bytes" in main_res:
@@ -518,8 +555,11 @@ def main():
         cx.dist.barrier()
     if cx.rank == 0:
         print(json.dumps(out), flush=True)
-    if cx.stuck:            # a bring-up thread still sits in RCCL: do not wait for it at interpreter exit
-        os._exit(0)
+    if cx.stuck:
+        # a bring-up thread still sits inside RCCL: the line above says so (exchange_fallback); this is a
+        # degraded run and the process says so too -- non-zero, and without waiting for that thread
+        sys.stdout.flush()
+        os._exit(4)
     if cx.dist is not None:
         cx.dist.destroy_process_group()
 

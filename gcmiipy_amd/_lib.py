@@ -39,6 +39,14 @@ class Config(C.Structure):
     ]
 
 
+class Exchange(C.Structure):
+    """gcm_exchange of include/gcmcore.h"""
+    _fields_ = [("comm", C.c_void_p), ("north", C.c_int32), ("south", C.c_int32),
+                ("send", C.c_void_p), ("recv", C.c_void_p), ("group_start", C.c_void_p), ("group_end", C.c_void_p),
+                ("send_north", C.c_void_p), ("send_south", C.c_void_p), ("recv_north", C.c_void_p),
+                ("recv_south", C.c_void_p)]
+
+
 _H = C.c_void_p
 # name -> (restype, argtypes); every symbol include/gcmcore.h declares
 SYMBOLS = {
@@ -76,6 +84,8 @@ SYMBOLS = {
     "gcm_step_interior": (C.c_int, [_H, C.c_double, C.c_void_p]),
     "gcm_step_boundary": (C.c_int, [_H, C.c_double, C.c_void_p]),
     "gcm_step_phase": (C.c_int, [_H, C.c_int, C.c_double, C.c_void_p]),
+    "gcm_set_exchange": (C.c_int, [_H, C.POINTER(Exchange)]),
+    "gcm_band_run": (C.c_int, [_H, C.c_int, C.c_double]),
     "gcm_sync": (C.c_int, [_H]),
     "gcm_advect2d": (C.c_int, [C.c_int] * 6 + [C.c_double] * 3 + [C.c_void_p] * 3),
     "gcm_pgf2d": (C.c_int, [C.c_int] * 3 + [C.c_double] * 3 + [C.c_void_p] * 3),

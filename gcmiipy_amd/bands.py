@@ -55,14 +55,19 @@ class BandRunner:
         steps_per_exchange, step_n(n, dt)               deep halo
     """
 
-    def __init__(self, engine, rank, nranks, dist=None):
+    def __init__(self, engine, rank, nranks, dist=None, north=None, south=None):
+        """north / south: ring neighbours, default (rank -+ 1) mod nranks (tests and tools run a band
+        that is its own neighbour on a one-rank communicator)"""
         self.e, self.rank, self.n, self.dist = engine, rank, nranks, dist
-        self.north = (rank - 1) % nranks
-        self.south = (rank + 1) % nranks
+        self.north = (rank - 1) % nranks if north is None else north
+        self.south = (rank + 1) % nranks if south is None else south
         self.k = getattr(engine, "steps_per_exchange", 1)
         self.count = 0
         self._ops = None
         self.primed = False
+        # an engine that can post the exchange itself (HipBandEngine over RCCL called directly, or the
+        # loopback stand-in) steps a whole run with ONE library call
+        self.native = nranks > 1 and hasattr(engine, "attach_ring") and engine.attach_ring(dist, self.north, self.south)
 
     def _pack(self):
         """-> (north send buffer, south send buffer), packed"""
@@ -136,6 +141,9 @@ class BandRunner:
     def run(self, nsteps, dt):
         """`nsteps` steps; with a deep halo the k local steps between two exchanges are one
         library call (no per-step host work)."""
+        if self.native:
+            self.e.band_run(nsteps, dt)
+            return
         if self.n > 1 and self.k > 1 and hasattr(self.e, "step_n"):
             done = 0
             while done < nsteps:
@@ -211,6 +219,27 @@ class HipBandEngine:
 
     def _s(self, stream):
         return stream.cuda_stream
+
+    def attach_ring(self, ring, north, south):
+        """-> True if the library can post this ring's exchange itself (gcm_set_exchange): RCCL called
+        directly (gcmiipy_amd.rccl.RcclP2P) or the loopback stand-in; GCM_BAND_HOST_LOOP=1 keeps the
+        host-driven sequence (the reference path of the tests)."""
+        import os
+        from .rccl import RcclP2P
+        if os.environ.get("GCM_BAND_HOST_LOOP") or not self.overlap:
+            return False
+        if isinstance(ring, RcclP2P):
+            rccl = ring
+        elif isinstance(ring, LoopbackExchange):
+            rccl = None
+        else:
+            return False
+        self.c.set_exchange(self.sbuf[0].data_ptr(), self.sbuf[1].data_ptr(), self.rbuf[0].data_ptr(),
+                            self.rbuf[1].data_ptr(), rccl, north, south)
+        return True
+
+    def band_run(self, n, dt):
+        self.c.band_run(n, dt)
 
     def send_buffer(self, side):
         self.c.halo_pack(side, self.sbuf[side].data_ptr(), self._s(self.compute))

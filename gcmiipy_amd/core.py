@@ -240,6 +240,22 @@ class Core:
         _check(lib.gcm_comm_stream(self._h, C.byref(out)), self._h)
         return out.value
 
+    def set_exchange(self, send_north, send_south, recv_north, recv_south, rccl=None, north=0, south=0):
+        """register the ghost-row exchange the library posts itself (gcm_set_exchange).  `rccl`: a
+        gcmiipy_amd.rccl.RcclP2P (its communicator and the addresses of its librccl entry points);
+        None: loopback, the band is its own neighbour (device-local copies)"""
+        x = _lib.Exchange()
+        x.north, x.south = north, south
+        x.send_north, x.send_south, x.recv_north, x.recv_south = send_north, send_south, recv_north, recv_south
+        if rccl is not None:
+            x.comm = rccl.comm
+            x.send, x.recv, x.group_start, x.group_end = rccl.entry_points()
+        _check(lib.gcm_set_exchange(self._h, C.byref(x)), self._h)
+
+    def band_run(self, nsteps, dt):
+        """`nsteps` full band steps, exchanges included, one library call (gcm_band_run)"""
+        _check(lib.gcm_band_run(self._h, int(nsteps), float(dt)), self._h)
+
     def step_interior(self, dt, stream=None):
         _check(lib.gcm_step_interior(self._h, float(dt), stream), self._h)
 

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -54,6 +55,11 @@ struct gcm_handle {
     size_t ev_used = 0;
 
     Pe25d *pe = nullptr;  // GCM_PE25D state (pe25d_kernels.h)
+
+    // gcm_band_run: the exchange the library posts itself
+    gcm_exchange xch{};
+    bool xch_set = false, primed = false;
+    hipEvent_t ev_pack = nullptr, ev_comm = nullptr;
 };
 
 #define HIPCHK(h, call)                                                                    \
@@ -118,6 +124,8 @@ int gcm_destroy(gcm_handle *h) {
     for (void *p : h->allocs) (void)hipFree(p);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->region_ev) (void)hipEventDestroy(e);
+    if (h->ev_pack) (void)hipEventDestroy(h->ev_pack);
+    if (h->ev_comm) (void)hipEventDestroy(h->ev_comm);
     delete h;
     return GCM_OK;
 }
@@ -259,6 +267,7 @@ static int xfer(gcm_handle *h, double *const dev[GCM_NFIELDS], const double *con
 int gcm_set_state(gcm_handle *h, const double *p, const double *u, const double *v,
                   const double *t, const double *q) {
     if (!h) return GCM_ERR_ARG;
+    h->primed = false;                                    // gcm_band_run: the new state's ghost rows are not exchanged yet
     if (h->pe) return pe25d_set(h->pe, false, p, u, v, t, q, h->stream, &h->err);
     const double *src[GCM_NFIELDS] = {p, u, v, t, q};
     h->star_valid = false;
@@ -629,12 +638,134 @@ int gcm_restore(gcm_handle *h) {
     }
     h->since_exchange = h->snap_since_exchange;
     h->star_valid = false;
+    h->primed = false;              // gcm_band_run: exchange the restored state's ghost rows first
     return GCM_OK;
 }
 
 int gcm_sync(gcm_handle *h) {
     if (!h) return GCM_ERR_ARG;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return GCM_OK;
+}
+
+int gcm_set_exchange(gcm_handle *h, const gcm_exchange *x) {
+    if (!h) return GCM_ERR_ARG;
+    if (h->wrap) return fail(h, GCM_ERR_STATE, "gcm_set_exchange: handle is not a latitude band");
+    if (!x) {
+        h->xch_set = false;
+        if (h->pe) return pe25d_set_halo_buffers(h->pe, nullptr, nullptr, h->stream, &h->err);
+        return GCM_OK;
+    }
+    const int nfn = (x->send != nullptr) + (x->recv != nullptr) + (x->group_start != nullptr) + (x->group_end != nullptr);
+    if (nfn != 0 && nfn != 4) return fail(h, GCM_ERR_ARG, "gcm_set_exchange: give all four RCCL entry points, or none (loopback)");
+    if (nfn == 4 && !x->comm) return fail(h, GCM_ERR_ARG, "gcm_set_exchange: communicator is NULL");
+    if (!x->send_north || !x->send_south || !x->recv_north || !x->recv_south)
+        return fail(h, GCM_ERR_ARG, "gcm_set_exchange: four device buffers of gcm_halo_bytes() are required");
+    if (h->cfg.device >= 0) HIPCHK(h, hipSetDevice(h->cfg.device));
+    void *cs = nullptr;
+    int rc = gcm_comm_stream(h, &cs);
+    if (rc) return rc;
+    if (!h->ev_pack) HIPCHK(h, hipEventCreateWithFlags(&h->ev_pack, hipEventDisableTiming));
+    if (!h->ev_comm) HIPCHK(h, hipEventCreateWithFlags(&h->ev_comm, hipEventDisableTiming));
+    h->xch = *x;
+    h->xch_set = true;
+    h->primed = false;
+    // GCM_PE25D: the edge rows of a stage are updated and packed into the send buffers on the
+    // handle's second stream (gcm_set_halo_buffers)
+    if (h->pe) return pe25d_set_halo_buffers(h->pe, x->send_north, x->send_south, h->stream, &h->err);
+    return GCM_OK;
+}
+
+}  // extern "C"
+
+// the send buffers are packed (or being packed: the caller has made the comm stream wait for that);
+// post the ring exchange on the comm stream, then unpack into the ghost rows on the compute stream
+static int band_exchange(gcm_handle *h) {
+    const gcm_exchange &x = h->xch;
+    const size_t nbytes = gcm_halo_bytes(h);
+    hipStream_t cs = h->comm;
+    if (x.send) {
+        int rc = x.group_start();
+        if (rc == 0) {
+            // north edge first, then the south ghost first: with two ranks both neighbours are the
+            // same peer and the i-th send must meet the peer's i-th receive
+            int r1 = x.send(x.send_north, nbytes, 0 /*ncclChar*/, x.north, x.comm, cs);
+            int r2 = r1 ? r1 : x.send(x.send_south, nbytes, 0, x.south, x.comm, cs);
+            int r3 = r2 ? r2 : x.recv(x.recv_south, nbytes, 0, x.south, x.comm, cs);
+            int r4 = r3 ? r3 : x.recv(x.recv_north, nbytes, 0, x.north, x.comm, cs);
+            const int re = x.group_end();                   // always closed, whatever a call returned
+            rc = r4 ? r4 : re;
+        }
+        if (rc != 0) {
+            char b[96];
+            snprintf(b, sizeof b, "gcm_band_run: RCCL call failed (ncclResult %d)", rc);
+            return fail(h, GCM_ERR_HIP, b);
+        }
+    } else {
+        // loopback: what goes north arrives as this band's own south ghost rows and vice versa
+        HIPCHK(h, hipMemcpyAsync(x.recv_south, x.send_north, nbytes, hipMemcpyDeviceToDevice, cs));
+        HIPCHK(h, hipMemcpyAsync(x.recv_north, x.send_south, nbytes, hipMemcpyDeviceToDevice, cs));
+    }
+    HIPCHK(h, hipEventRecord(h->ev_comm, cs));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_comm, 0));
+    return gcm_halo_unpack2(h, x.recv_north, x.recv_south, h->stream);
+}
+
+// pack both edges on the compute stream, then exchange (the comm stream waits for the pack only)
+static int band_pack_exchange(gcm_handle *h) {
+    int rc = gcm_halo_pack2(h, h->xch.send_north, h->xch.send_south, h->stream);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev_pack, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->comm, h->ev_pack, 0));
+    return band_exchange(h);
+}
+
+extern "C" {
+
+int gcm_band_run(gcm_handle *h, int nsteps, double dt) {
+    if (!h || nsteps < 0) return GCM_ERR_ARG;
+    if (h->wrap) return fail(h, GCM_ERR_STATE, "gcm_band_run: handle is not a latitude band");
+    if (!h->xch_set) return fail(h, GCM_ERR_STATE, "gcm_band_run: no exchange registered (gcm_set_exchange)");
+    if (h->cfg.device >= 0) HIPCHK(h, hipSetDevice(h->cfg.device));
+    int rc = GCM_OK;
+    if (h->pe) {
+        if (!h->primed) {                                  // ghost rows of the initial state, once
+            if ((rc = band_pack_exchange(h))) return rc;
+            h->primed = true;
+        }
+        for (int n = 0; n < nsteps; ++n)
+            for (int stage = 0; stage < 2; ++stage) {
+                // edge rows + pack on the second stream, interior rows on the compute stream, then the
+                // exchange behind the pack: it overlaps the interior rows
+                if ((rc = pe25d_step_phase(h->pe, 2 * stage, dt, h->stream, &h->err))) return rc;
+                if ((rc = pe25d_step_phase(h->pe, 2 * stage + 1, dt, h->stream, &h->err))) return rc;
+                if ((rc = pe25d_wait_edges(h->pe, h->comm, &h->err))) return rc;
+                if ((rc = band_exchange(h))) return rc;
+            }
+        return GCM_OK;
+    }
+    const int k = h->G / kGhost;                            // steps per exchange
+    int done = 0;
+    while (done < nsteps) {
+        if (k == 1) {
+            // one exchange per step, overlapped with the rows that need no ghost data
+            if ((rc = gcm_halo_pack2(h, h->xch.send_north, h->xch.send_south, h->stream))) return rc;
+            HIPCHK(h, hipEventRecord(h->ev_pack, h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->comm, h->ev_pack, 0));
+            if ((rc = gcm_step_interior(h, dt, h->stream))) return rc;
+            if ((rc = band_exchange(h))) return rc;
+            if ((rc = gcm_step_boundary(h, dt, h->stream))) return rc;
+            ++done;
+            continue;
+        }
+        if (!h->primed || h->since_exchange >= k) {
+            if ((rc = band_pack_exchange(h))) return rc;
+            h->primed = true;
+        }
+        const int n = std::min(k - h->since_exchange, nsteps - done);
+        if ((rc = gcm_step(h, n, dt))) return rc;
+        done += n;
+    }
     return GCM_OK;
 }
 

@@ -70,19 +70,34 @@ class RcclP2P:
         def wait(self):                 # stream-ordered: whoever waits for the stream has the data
             pass
 
-    def __init__(self, bootstrap, rank, world):
+    def __init__(self, bootstrap, rank, world, uid_bytes=None):
+        """uid_bytes: the 128-byte ncclUniqueId if the caller has distributed it already (bench.py does,
+        so that a rank that fails before the broadcast cannot leave the others waiting in it)"""
         import torch
         self.torch, self.rank, self.world = torch, rank, world
         self.lib = _load()
-        uid = _UniqueId()
-        if rank == 0:
-            self._check(self.lib.ncclGetUniqueId(C.byref(uid)))
-        if world > 1:
-            box = [uid_to_bytes(uid) if rank == 0 else None]
-            bootstrap.broadcast_object_list(box, src=0)
-            uid = uid_from_bytes(box[0])
+        if uid_bytes is not None:
+            uid = uid_from_bytes(uid_bytes)
+        else:
+            uid = _UniqueId()
+            if rank == 0:
+                self._check(self.lib.ncclGetUniqueId(C.byref(uid)))
+            if world > 1:
+                box = [uid_to_bytes(uid) if rank == 0 else None]
+                bootstrap.broadcast_object_list(box, src=0)
+                uid = uid_from_bytes(box[0])
         self.comm = C.c_void_p()
         self._check(self.lib.ncclCommInitRank(C.byref(self.comm), world, uid, rank))
+
+    @staticmethod
+    def new_unique_id():
+        """-> 128 bytes (rank 0 calls this; the caller carries them to the other ranks)"""
+        lib = _load()
+        uid = _UniqueId()
+        rc = lib.ncclGetUniqueId(C.byref(uid))
+        if rc != 0:
+            raise RcclError("rccl: %s" % lib.ncclGetErrorString(rc).decode())
+        return uid_to_bytes(uid)
 
     def _check(self, rc):
         if rc != 0:
@@ -94,12 +109,21 @@ class RcclP2P:
         stream = C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
         lib, comm = self.lib, self.comm
         self._check(lib.ncclGroupStart())
-        for o in ops:
-            t = o.tensor
-            fn = lib.ncclSend if o.op == "isend" else lib.ncclRecv
-            self._check(fn(C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), _NCCL_CHAR, o.peer, comm, stream))
-        self._check(lib.ncclGroupEnd())
+        try:
+            for o in ops:
+                t = o.tensor
+                fn = lib.ncclSend if o.op == "isend" else lib.ncclRecv
+                self._check(fn(C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), _NCCL_CHAR, o.peer, comm, stream))
+        finally:
+            rc = lib.ncclGroupEnd()        # a failed send must not leave the group open
+        self._check(rc)
         return [self._Done()]
+
+    def entry_points(self):
+        """addresses of ncclSend, ncclRecv, ncclGroupStart, ncclGroupEnd in the loaded librccl.so, for
+        gcm_set_exchange (the C library posts the exchange itself: Core.band_run)"""
+        lib = self.lib
+        return tuple(C.cast(f, C.c_void_p).value for f in (lib.ncclSend, lib.ncclRecv, lib.ncclGroupStart, lib.ncclGroupEnd))
 
     def self_check(self):
         """one ring shift of a small tensor (to the south neighbour, from the north one) on the

@@ -228,6 +228,29 @@ int gcm_set_halo_buffers(gcm_handle *h, void *north_send, void *south_send);
 int gcm_comm_stream(gcm_handle *h, void **stream);
 int gcm_wait_edges(gcm_handle *h, void *stream);
 
+/* The whole band step inside the library: one call per run instead of ~16 per step from the host.
+ * gcm_set_exchange hands the library what it needs to post the ghost-row exchange itself -- the
+ * RCCL communicator, the two ring neighbours, the addresses of ncclSend / ncclRecv / ncclGroupStart /
+ * ncclGroupEnd in the librccl.so the process already has loaded (the library does not link RCCL), and
+ * four DEVICE buffers of gcm_halo_bytes() each.  With all four function pointers NULL the exchange is
+ * a device-local copy (the band is its own neighbour on both sides: the periodic single domain;
+ * tests and the one-GPU scaling tools).  gcm_band_run then runs `nsteps` full steps, exchanges
+ * included (GCM_PE25D: two per step, posted on the handle's comm stream behind the edge rows and
+ * overlapped with the interior rows; 2-D models: one per halo_steps steps), asynchronously on the
+ * handle's streams.  The sequence is the one gcm_step_phase / gcm_halo_* document, so the results
+ * are bit-identical to a host-driven band.                                                       */
+typedef int (*gcm_p2p_fn)(const void *buf, size_t count, int datatype, int peer, void *comm, void *stream);
+typedef int (*gcm_group_fn)(void);
+typedef struct {
+    void *comm;               /* ncclComm_t */
+    int32_t north, south;     /* ranks of the ring neighbours in that communicator */
+    gcm_p2p_fn send, recv;    /* ncclSend, ncclRecv   (bytes are sent as ncclChar) */
+    gcm_group_fn group_start, group_end;
+    void *send_north, *send_south, *recv_north, *recv_south;
+} gcm_exchange;
+int gcm_set_exchange(gcm_handle *h, const gcm_exchange *x);   /* NULL: unregister */
+int gcm_band_run(gcm_handle *h, int nsteps, double dt);
+
 int gcm_sync(gcm_handle *h);
 
 /* Stand-alone 2-D operators of two_d.py on velocity stacks V[axis] (host arrays in/out; V is

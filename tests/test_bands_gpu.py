@@ -412,12 +412,15 @@ def _rccl_self_worker(rank, port, model, outdir):
     from gcmiipy_amd.bands import BandRunner, HipBandEngine
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
-    direct = model.endswith("-direct")          # gcmiipy_amd.rccl: RCCL called through ctypes
+    direct = "-direct" in model                 # gcmiipy_amd.rccl: RCCL called through ctypes
+    if model.endswith("-hostloop"):             # the host-driven sequence instead of gcm_band_run
+        os.environ["GCM_BAND_HOST_LOOP"] = "1"
     model = model.split("-")[0]
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     if direct:
         from gcmiipy_amd.rccl import RcclP2P
-        ring = RcclP2P(None, 0, 1)
+        ring = RcclP2P(None, 0, 1, uid_bytes=RcclP2P.new_unique_id())   # bench.py's bring-up path
+        ring.self_check()
     else:
         ring = dist
     if model == "pe":
@@ -433,9 +436,10 @@ def _rccl_self_worker(rank, port, model, outdir):
                    halo_steps=1 if model == "c3" else 4)
         c.set_state(**_ic2d((H, W)))
     eng = HipBandEngine(c, torch)                 # stream-aware: the exchange is ordered on streams only
-    runner = BandRunner(eng, 0, 2, ring)
-    runner.north = runner.south = 0
-    runner.run(steps, dt)
+    runner = BandRunner(eng, 0, 2, ring, north=0, south=0)
+    assert runner.native == (direct and "GCM_BAND_HOST_LOOP" not in os.environ)
+    runner.run(steps - 2, dt)
+    runner.run(2, dt)                             # a second call continues on the exchanged ghosts
     torch.cuda.synchronize()
     st = c.get_state()
     np.savez(os.path.join(outdir, "self.npz"), **{k: a for k, a in zip("puvtq", st) if a is not None})
@@ -445,10 +449,13 @@ def _rccl_self_worker(rank, port, model, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model", ["pe-direct", "c3-direct", "c3deep-direct", "pe", "c3deep"])
+@pytest.mark.parametrize("model", ["pe-direct", "c3-direct", "c3deep-direct", "pe-direct-hostloop",
+                                   "c3deep-direct-hostloop", "pe", "c3deep"])
 def test_band_runner_over_rccl_self_ring(tmp_path, model):
     """The production exchange paths on the one GPU of the test box -- RCCL called directly
-    (gcmiipy_amd.rccl: ncclSend/ncclRecv groups on the library's comm stream; what bench.py uses)
+    (gcmiipy_amd.rccl: ncclSend/ncclRecv groups on the library's comm stream, posted by the LIBRARY
+    inside gcm_band_run, one call per run: what bench.py uses; "-hostloop": the same exchange posted
+    from Python step by step)
     and through torch.distributed "nccl" (batch_isend_irecv) -- with no host synchronisation.  RCCL
     refuses two ranks per device, but a rank may send to itself, and a band that is its own
     neighbour on both sides is the periodic single domain.  Bit-identical to it (GCM_PE25D: edge
@@ -474,3 +481,46 @@ def test_band_runner_over_rccl_self_ring(tmp_path, model):
     ref.close()
     for k, w in zip("puvtq", want):
         assert np.array_equal(got[k], w), k
+
+
+@pytest.mark.parametrize("model", ["pe", "c3", "c3deep"])
+def test_band_run_native_loopback_equals_single_domain(model):
+    """gcm_band_run with the loopback exchange (gcm_set_exchange without RCCL entry points): the band
+    is its own neighbour, i.e. the periodic single domain -- bit-identical to it, and to the
+    host-driven sequence.  Also the error paths of gcm_set_exchange / gcm_band_run."""
+    import torch
+    import gcmiipy_amd as g
+    from gcmiipy_amd import geometry
+    from gcmiipy_amd.bands import BandRunner, HipBandEngine, LoopbackExchange
+    from gcmiipy_amd.core import GcmError
+    if model == "pe":
+        H, W, L, steps, dt = 23, 36, 9, 5, 120.0
+        geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+        mk = lambda **kw: g.Core(g._lib.PE25D, W, H, L, geom=geom, **kw)
+        ic = dict(zip(("p", "u", "v", "t", "q"), _ic_pe(geom)))
+    else:
+        H, W, steps, dt = 64, 130, 11, 300.0
+        mk = lambda **kw: g.Core(g._lib.SW2D_TEMP, W, H, dx=300e3, tracer=g._lib.TRACER_VANLEER, **kw)
+        ic = _ic2d((H, W))
+    ref = mk()
+    ref.set_state(**ic)
+    ref.step(steps, dt)
+    want = ref.get_state()
+    with pytest.raises(GcmError, match="not a latitude band"):
+        ref.band_run(1, dt)
+    ref.close()
+    c = mk(nranks=2, rank=0, global_height=H, row0=0, stream=torch.cuda.current_stream().cuda_stream,
+           halo_steps=4 if model == "c3deep" else 1)
+    c.set_state(**ic)
+    with pytest.raises(GcmError, match="no exchange registered"):
+        c.band_run(1, dt)
+    eng = HipBandEngine(c, torch)
+    runner = BandRunner(eng, 0, 2, LoopbackExchange(), north=0, south=0)
+    assert runner.native
+    runner.run(3, dt)
+    runner.run(steps - 3, dt)
+    torch.cuda.synchronize()
+    got = c.get_state()
+    c.close()
+    for k, a, b in zip("puvtq", got, want):
+        assert (a is None and b is None) or np.array_equal(a, b), k

@@ -64,9 +64,9 @@ def main():
         if model != "PE25D":
             core.snapshot()
         eng = HipBandEngine(core, torch) if n > 1 else None
-        runner = BandRunner(eng, rank, n, (tdist if tdist is not None else LoopbackDist()) if n > 1 else None)
-        if tdist is not None:
-            runner.north = runner.south = 0
+        # the exchange goes to the band itself (one-rank communicator / device-local copy): neighbours = rank 0
+        runner = BandRunner(eng, rank, n, (tdist if tdist is not None else LoopbackDist()) if n > 1 else None,
+                            north=0 if n > 1 else None, south=0 if n > 1 else None)
         if n == 1:
             runner.e = type("E", (), {"step_all": staticmethod(lambda dt_: core.step(1, dt_))})()
         import time
@@ -104,7 +104,8 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / steps
         assert core.diag(_lib.DIAG_ANY_NAN) == 0.0, "state went NaN: timing invalid"
-        res.append({"split": n, "band_rows": nrows, "halo_steps": k, "ms_per_step": ms, "host_ms_per_step": host_ms})
+        res.append({"split": n, "band_rows": nrows, "halo_steps": k, "ms_per_step": ms, "host_ms_per_step": host_ms,
+                    "one_library_call_per_run": bool(getattr(runner, "native", False))})
         print("N=%d  band of %4d rows  %.4f ms/step  (host queues a step in %.4f ms)" % (n, nrows, ms, host_ms), flush=True)
         core.close()
     base = res[0]["ms_per_step"] if res and res[0]["split"] == 1 else None
