@@ -1703,6 +1703,8 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         }
         if (mode == 1 && async_edges(m) && m->aux) (void)hipEventRecord(m->ev_a, s);
         a.j1 = j1;
+        // (a looping form of this filter, as K1's, was built and is 25 % SLOWER: its requests and the
+        // per-column thermodynamics push it to 187 VGPRs, two waves per SIMD instead of four)
         hipLaunchKernelGGL(pgf_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, s2, a);
         if (m->aux) {
             (void)hipEventRecord(m->ev_join, m->aux);
