@@ -1516,16 +1516,19 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
         return nullptr;
     }
     {
-        // K4 runs 8 one-wave workgroups per CU (2 waves/SIMD); a band with fewer workgroups than
-        // about 2.5 rounds of that splits the level march, so that the kernel is several short
-        // rounds instead of one or two long ones (results do not depend on the split; measured
-        // on 1440 columns: 90 rows best with 2-3 segments, 180 with 2, 360 and more with 1)
+        // K4 keeps 8 waves per CU resident (2 per SIMD), one row x 62 columns each.  A band with less than
+        // about a round and a half of them splits the level march, so that the launch is several short
+        // rounds instead of one long one (results do not depend on the split).  Measured on 1440 columns
+        // x 24 levels: 90 rows best with 2 segments, 180 and more with 1.  Short bands also take the
+        // 3-row workgroups (two per CU, out of step with each other: 3-5 % faster up to ~200 rows; the
+        // 7-row form reads the halo rows 9/7 instead of 5/3 times and is kept where bytes matter).
         int dev = 0, cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         m->cus = cus;
-        const long tiles = (long)((W + kUpdThreads - 1) / kUpdThreads) * m->H;
-        long want = (5L * 8 * cus / 2 + tiles - 1) / tiles;
+        const double rounds = (double)((W + kUpdCols - 1) / kUpdCols) * m->H / (8.0 * cus);
+        long want = (long)std::ceil(1.5 / std::max(rounds, 1e-3));
+        m->upd_rows = m->H <= 256 ? 3 : 7;
         if (const char *e = getenv("GCM_PE_LEVEL_SEGMENTS")) want = atoi(e);
         if (const char *e = getenv("GCM_PE_UPDATE_ROWS")) {      // 0: the one-wave update kernel; 3, 7: rows per group
             const int v = atoi(e);
@@ -1890,6 +1893,20 @@ int pe25d_set_halo_buffers(Pe25d *m, void *north, void *south, hipStream_t s, st
     m->send_buf[1] = south;
     m->edges_pending = false;
     return GCM_OK;
+}
+
+// host-side step state (which state set is current, ...): gcm_band_run replays a captured step as a
+// hipGraph, which runs none of the host code that advances this state
+void pe25d_host_state(Pe25d *m, bool save, int st[4]) {
+    if (save) { st[0] = m->cur_i; st[1] = m->star_valid; st[2] = m->pack_set; st[3] = m->edges_pending; }
+    else { m->cur_i = st[0]; m->star_valid = st[1] != 0; m->pack_set = st[2]; m->edges_pending = st[3] != 0; }
+}
+int pe25d_parity(const Pe25d *m) { return m->cur_i; }
+void pe25d_advance_step(Pe25d *m) {          // what one full band step (phases 0..3) leaves behind
+    m->cur_i = 1 - m->cur_i;
+    m->star_valid = false;
+    m->pack_set = -1;
+    m->edges_pending = false;
 }
 
 int pe25d_wait_edges(Pe25d *m, hipStream_t s, std::string *err) {

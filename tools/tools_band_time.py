@@ -47,6 +47,8 @@ def main():
         from gcmiipy_amd.rccl import RcclP2P
         tdist = RcclP2P(None, 0, 1)
     desc, H, W, L, model, tracer, bpc, dt = bench.WORKLOADS[a.workload]
+    # a stream of its own, as bench.py's bands use (a step captured as a hipGraph cannot live on the null stream)
+    torch.cuda.set_stream(torch.cuda.Stream())
     geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig) if model == "PE25D" else None
     full = bench.synth(a.workload, H, W, L, geom=geom)
     res = []
