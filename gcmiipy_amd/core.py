@@ -51,6 +51,12 @@ class Core:
                  global_height=None, row0=0, device=-1, stream=None, halo_steps=1, coriolis=False, dtype="f64"):
         self.model, self.W, self.H, self.L = model, int(width), int(height), int(layers)
         self.nranks, self.rank = nranks, rank
+        # what a checkpoint needs to rebuild this handle (checkpoint.save / restore)
+        self.options = dict(dx=float(dx), tracer=int(tracer), variant=int(variant), filter=bool(filter),
+                            nranks=int(nranks), rank=int(rank), row0=int(row0), halo_steps=int(halo_steps),
+                            coriolis=bool(coriolis), dtype=dtype,
+                            global_height=int(height if global_height is None else global_height))
+        self.has_ground = False
         cfg = _lib.Config()
         cfg.abi_version = _lib.ABI_VERSION
         cfg.model = model
@@ -182,6 +188,7 @@ class Core:
     # -- column physics (GCM_PE25D) ----------------------------------------------------
     def set_ground(self, gt):
         _check(lib.gcm_set_ground(self._h, _ptr(as_f64(gt, (self.H, self.W), "gt"))), self._h)
+        self.has_ground = True
 
     def get_ground(self):
         out = np.empty((self.H, self.W))

@@ -286,7 +286,10 @@ const char *gcm_ops_last_error(void);
 /* Timing helper for bench.py: runs nsteps steps bracketed by HIP events on the
  * handle's stream; returns elapsed milliseconds in *ms and, in *kernel_ms_avg,
  * the mean duration of the dominant kernel's launches measured by per-launch
- * event pairs in a second pass (so the first figure carries no event overhead). */
+ * event pairs in a second pass (so the first figure carries no event overhead).
+ * NOTE: with kernel_ms_avg != NULL the state advances 2 * nsteps steps (the second
+ * pass re-runs the same number of steps).  GCM_DIAG_ANY_NAN looks at u only, as the
+ * reference's watch does (np.isnan(u).any(), matsuno_c_grid.py:184-187).            */
 int gcm_time_steps(gcm_handle *h, int nsteps, double dt, double *ms, double *kernel_ms_avg);
 
 #ifdef __cplusplus

@@ -216,6 +216,56 @@ def test_checkpoint_resume_bit_exact(g, tmp_path):
     b.close()
 
 
+def test_checkpoint_is_self_contained(g, tmp_path):
+    """a handle with the column physics, Coriolis terms and fp32 storage, and a 2-D handle with the
+    tracer: restore() needs nothing but the file, and the resumed runs match the uninterrupted ones"""
+    from gcmiipy_amd import geometry, checkpoint
+    d = golden("g8_pe25d")
+    geom = geometry.gen_geometry(24, 36, 9, sig_func=geometry.manabe_sig)
+    ic = [d["dense_%s0" % k] for k in "puvtq"]
+    gt = np.full((24, 36), 288.0)
+    for dtype in ("f64", "f32"):
+        a = g.Core(g._lib.PE25D, 36, 24, 9, geom=geom, coriolis=True, dtype=dtype)
+        a.set_state(*ic)
+        a.set_ground(gt)
+        for n in range(2):
+            a.step(1, 300.0)
+            a.solar_step(geom, 300.0, n * 300.0)
+        path = str(tmp_path / ("ck_%s.npz" % dtype))
+        checkpoint.save(path, a, step=2, time=600.0, geom=geom)
+        for n in range(2, 4):
+            a.step(1, 300.0)
+            a.solar_step(geom, 300.0, n * 300.0)
+        want, want_gt = a.get_state(), a.get_ground()
+        a.close()
+        b, ck = checkpoint.restore(path)
+        assert b.dtype == dtype and b.options["coriolis"] and b.has_ground
+        for n in range(2, 4):
+            b.step(1, 300.0)
+            b.solar_step(ck["geom"], 300.0, n * 300.0)
+        for x, y in zip(b.get_state(), want):
+            assert np.array_equal(x, y), dtype
+        assert np.array_equal(b.get_ground(), want_gt)
+        b.close()
+    rng = np.random.default_rng(4)
+    f = dict(u=rng.standard_normal((16, 40)), v=rng.standard_normal((16, 40)), p=101325 + rng.standard_normal((16, 40)),
+             t=273.16 + rng.standard_normal((16, 40)), q=rng.random((16, 40)))
+    a = g.Core(g._lib.SW2D_TEMP, 40, 16, dx=300e3, tracer=g._lib.TRACER_UPWIND, variant=g._lib.VARIANT_STAGED)
+    a.set_state(**f)
+    a.step(3, 300.0)
+    path = str(tmp_path / "ck2d.npz")
+    checkpoint.save(path, a, step=3)
+    a.step(2, 300.0)
+    want = a.get_state()
+    a.close()
+    b, ck = checkpoint.restore(path)                       # dx, the upwind tracer and the staged variant come from the file
+    assert b.options["tracer"] == g._lib.TRACER_UPWIND and b.options["dx"] == 300e3
+    b.step(2, 300.0)
+    for x, y in zip(b.get_state(), want):
+        assert (x is None and y is None) or np.array_equal(x, y)
+    b.close()
+
+
 def test_coriolis_option_vs_golden(g):
     """optional Coriolis terms (dynamics.py:82-92, off in the reference) vs the reference's own
     expressions run with the switch flipped (G12)"""
