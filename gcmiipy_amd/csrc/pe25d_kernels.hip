@@ -720,14 +720,21 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
     const Idx ix{a.W, a.H, a.L, a.wrap};
     const int W = a.W, L = a.L;
     const int ncol = (W + kUpdCols - 1) / kUpdCols;
-    const int per_xcd = gridDim.x / 8;
-    const int wg = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    // wg = ((row group, level segment), column tile); groups come from [j0, j1) then [jb0, jb1)
+    // Workgroup = ((row group, level segment), column tile); groups come from [j0, j1) then [jb0, jb1).
+    // Each XCD (workgroups b, b+8, ... share one) takes a contiguous run of (group, segment) pairs and
+    // walks it with the GROUP index fastest: the workgroups resident on an XCD at one time are
+    // vertically adjacent groups of a few column tiles, marching in step, so the halo row one of them
+    // requests is the own row its neighbour requests at about the same time -- it comes from that
+    // XCD's L2 instead of HBM.
     const int nseg = a.nseg;
-    const int rowseg = wg / ncol, ct = wg - rowseg * ncol;
-    const int grp = rowseg / nseg, seg = rowseg - grp * nseg;
     const int na = a.j1 - a.j0, nb = a.jb1 - a.jb0;
     const int ga = (na + R - 1) / R, gb = (nb + R - 1) / R;
+    const int per_xcd = gridDim.x / 8;                           // = rs_per_xcd * ncol (launch)
+    const int rs_per_xcd = per_xcd / ncol;
+    const int l = blockIdx.x / 8;
+    const int ct = l / rs_per_xcd;
+    const int rowseg = (blockIdx.x % 8) * rs_per_xcd + (l - ct * rs_per_xcd);
+    const int grp = rowseg / nseg, seg = rowseg - grp * nseg;
     if (grp >= ga + gb) return;                                  // padding workgroups (uniform)
     const int jg = grp < ga ? a.j0 + grp * R : a.jb0 + (grp - ga) * R;
     const int jend = min(jg + R, grp < ga ? a.j1 : a.jb1);
@@ -755,7 +762,7 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
             const long kl = (long)k * W;
             d[0] = a.su[rn + kl + i]; d[1] = a.sv[rn + kl + i]; d[2] = a.st[rn + kl + i]; d[3] = a.sq[rn + kl + i];
             d[4] = a.su[rs + kl + i]; d[5] = a.sv[rs + kl + i]; d[6] = a.st[rs + kl + i]; d[7] = a.sq[rs + kl + i];
-            d[8] = a.spu[rs + kl + i]; d[9] = a.phi[rs + kl + i];
+            d[8] = a.spu[rs + kl + i]; d[9] = a.phi[rs + (long)(k & ~1) * W + i];
         };
         const auto put = [&](const T (&d)[10], int buf) {
             T *t = t0 + buf * kBuf;
@@ -821,7 +828,8 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
     T q[2][11];
     const auto load = [&](T (&d)[11], int k) {
         const long o = rc + (long)k * W + i;
-        d[0] = a.su[o]; d[1] = a.sv[o]; d[2] = a.st[o]; d[3] = a.sq[o]; d[4] = a.spu[o]; d[5] = a.phi[o]; d[6] = a.pgfu[o];
+        d[0] = a.su[o]; d[1] = a.sv[o]; d[2] = a.st[o]; d[3] = a.sq[o]; d[4] = a.spu[o]; d[6] = a.pgfu[o];
+        d[5] = a.phi[rc + (long)(k & ~1) * W + i];           // the anchor at or below k (odd k: unused, and a cache hit)
         if (!same) { d[7] = a.u[o]; d[8] = a.v[o]; d[9] = a.t[o]; d[10] = a.q[o]; }
     };
     const auto put = [&](const T (&d)[11], int buf) {
@@ -1724,8 +1732,9 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         if (m->upd_rows > 0) {
             const int Rg = m->upd_rows;
             const long groups = (std::max(0, r1 - r0) + Rg - 1) / Rg + (std::max(0, rb1 - rb0) + Rg - 1) / Rg;
-            const long wgs = (long)((W + kUpdCols - 1) / kUpdCols) * groups * a.nseg;
-            const dim3 gg((unsigned)((wgs + 7) / 8 * 8));
+            // 8 XCDs x (row group, segment) pairs per XCD x column tiles (see the kernel's index map)
+            const long rs_per_xcd = (groups * a.nseg + 7) / 8;
+            const dim3 gg((unsigned)(8 * rs_per_xcd * ((W + kUpdCols - 1) / kUpdCols)));
             const size_t lds = upd_lds_bytes<T>(Rg, L);
             const bool same = a.u == a.su;
             if (Rg == 7 && same) hipLaunchKernelGGL((pe_update_rows_kernel<T, 7, true>), gg, dim3(64 * 8), lds, st, a);
