@@ -40,8 +40,8 @@ def _ic2d(shape, temp):
 def _worker_2d(rank, world, port, shape, temp, steps, outdir, halo_steps=1):
     from band_engines import NumpyBand2D
     from gcmiipy_amd.bands import BandRunner, split_rows
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rendezvous through a file in the test's own directory: no TCP port to collide on
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(outdir, "rendezvous"), rank=rank, world_size=world)
     full = _ic2d(shape, temp)
     row0, n = split_rows(shape[0], world)[rank]
     log = []
@@ -63,8 +63,8 @@ def _worker_pe(rank, world, port, hwl, steps, outdir, edge_first=False):
     from band_engines import NumpyBandPE
     from gcmiipy_amd.bands import BandRunner, split_rows
     from oracle import geometry as ogeo
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rendezvous through a file in the test's own directory: no TCP port to collide on
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(outdir, "rendezvous"), rank=rank, world_size=world)
     H, W, L = hwl
     geom = ogeo.gen_geometry(H, W, L, sig_func=ogeo.manabe_sig)
     geom.heightmap[H // 2, 3] = 300.0

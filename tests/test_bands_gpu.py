@@ -310,7 +310,6 @@ def _worker(rank, world, port, model, outdir):
     import gcmiipy_amd as g
     from gcmiipy_amd import geometry
     from gcmiipy_amd.bands import BandRunner, HipBandEngine, split_rows
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if model in ("c3", "c3deep"):
@@ -410,13 +409,13 @@ def _rccl_self_worker(rank, port, model, outdir):
     import gcmiipy_amd as g
     from gcmiipy_amd import geometry
     from gcmiipy_amd.bands import BandRunner, HipBandEngine
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     direct = "-direct" in model                 # gcmiipy_amd.rccl: RCCL called through ctypes
     if model.endswith("-hostloop"):             # the host-driven sequence instead of gcm_band_run
         os.environ["GCM_BAND_HOST_LOOP"] = "1"
     model = model.split("-")[0]
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.init_process_group("nccl", init_method="file://" + os.path.join(outdir, "rendezvous"), rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
     if direct:
         from gcmiipy_amd.rccl import RcclP2P
         ring = RcclP2P(None, 0, 1, uid_bytes=RcclP2P.new_unique_id())   # bench.py's bring-up path
