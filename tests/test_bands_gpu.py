@@ -311,7 +311,8 @@ def _worker(rank, world, port, model, outdir):
     from gcmiipy_amd import geometry
     from gcmiipy_amd.bands import BandRunner, HipBandEngine, split_rows
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rendezvous through a file in the test's own directory: no TCP port to collide on
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(outdir, "rendezvous"), rank=rank, world_size=world)
     if model in ("c3", "c3deep"):
         H, W, steps, dt = 40, 130, 3 if model == "c3" else 4, 300.0
         f = _ic2d((H, W))
