@@ -89,6 +89,8 @@ SYMBOLS = {
     "gcm_sync": (C.c_int, [_H]),
     "gcm_advect2d": (C.c_int, [C.c_int] * 6 + [C.c_double] * 3 + [C.c_void_p] * 3),
     "gcm_pgf2d": (C.c_int, [C.c_int] * 3 + [C.c_double] * 3 + [C.c_void_p] * 3),
+    "gcm_pe1d": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_void_p * 4),
+                           C.POINTER(C.c_void_p * 4), C.POINTER(C.c_void_p * 4)]),
     "gcm_ops_last_error": (C.c_char_p, []),
     "gcm_time_steps": (C.c_int, [_H, C.c_int, C.c_double, _dp, _dp]),
 }

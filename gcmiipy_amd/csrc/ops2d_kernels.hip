@@ -147,6 +147,56 @@ __global__ __launch_bounds__(256) void flux_limiter_kernel(int kind, int n, cons
     }
 }
 
+// 1-D Matsuno of p, u, theta, q in momentum form on a periodic line (no_limits.py:50-152; BASELINE
+// configs[0]): one Euler stage, one thread per cell.  iph(x) = (x + ip(x))/2, imh(x) = (im(x) + x)/2,
+// div(q_h) = (q_h - im(q_h))/dx, gradh(q) = (ip(q) - q)/dx (coordinates_1d.py:25-53).  u_n needs
+// iph(p_n), so a thread forms p_n of its own cell and of the next.
+struct Pe1dArgs {
+    const double *p, *u, *t, *q;          // base state
+    const double *sp, *su, *st, *sq;      // stage state
+    double *po, *uo, *to, *qo;
+    const double *exner_tab;
+    int n;
+    double dt, dx;
+};
+__global__ __launch_bounds__(256) void pe1d_half_kernel(Pe1dArgs a) {
+    __shared__ double tab[kExnerTabDoubles];
+    tab[threadIdx.x] = a.exner_tab[threadIdx.x];
+    __syncthreads();
+    const int n = a.n, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int im = i == 0 ? n - 1 : i - 1, ip = i + 1 == n ? 0 : i + 1, ipp = ip + 1 == n ? 0 : ip + 1;
+    const double dt = a.dt, dx = a.dx;
+    const double sp_m = a.sp[im], sp_c = a.sp[i], sp_p = a.sp[ip], sp_pp = a.sp[ipp];
+    const double su_m = a.su[im], su_c = a.su[i], su_p = a.su[ip];
+    const double st_m = a.st[im], st_c = a.st[i], st_p = a.st[ip];
+    const double sq_m = a.sq[im], sq_c = a.sq[i], sq_p = a.sq[ip];
+    const double spu_m = su_m * ((sp_m + sp_c) / 2), spu_c = su_c * ((sp_c + sp_p) / 2), spu_p = su_p * ((sp_p + sp_pp) / 2);
+    // advec_q, no_limits.py:50-62
+    const double q_n = a.q[i] - (((((sq_c + sq_p) / 2) * su_c) - (((sq_m + sq_c) / 2) * su_m)) / dx) * dt;
+    // advec_p, :73-75
+    const double p_n = a.p[i] - ((spu_c - spu_m) / dx) * dt;
+    const double p_np = a.p[ip] - ((spu_p - spu_c) / dx) * dt;
+    // advec_pu, :78-92
+    const double um = (su_m + su_c) / 2, up = (su_c + su_p) / 2;
+    const double adv_pu = ((up * up) * ((sp_c + sp_p) / 2) - (um * um) * sp_c) / dx;
+    // pgf, :102-115: rho at the half point from to_true_temp(iph(t), iph(p))
+    const double pph = (sp_c + sp_p) / 2, tph = (st_c + st_p) / 2;
+    const double tt = tph * exner(pph, tab);
+    const double rho = pph / (kRd * tt);
+    const double pgf = pph / rho * ((sp_p - sp_c) / dx);
+    const double pu = a.u[i] * ((a.p[i] + a.p[ip]) / 2);
+    const double pu_n = pu - (adv_pu + pgf) * dt;
+    const double u_n = pu_n / ((p_n + p_np) / 2);
+    // advec_t, :95-97
+    const double adv_t = (spu_c * ((st_c + st_p) / 2) - spu_m * ((st_m + st_c) / 2)) / dx;
+    const double t_n = a.t[i] - (adv_t / p_n) * dt;
+    a.po[i] = p_n;
+    a.uo[i] = u_n;
+    a.to[i] = t_n;
+    a.qo[i] = q_n;
+}
+
 thread_local std::string g_ops_error;
 int ops_fail(int code, const char *m) { g_ops_error = m; return code; }
 }  // namespace
@@ -192,6 +242,44 @@ int gcm_advect2d(int scheme, int axes, int finite, int width, int height, int ns
     }
     if (hipMemcpy(q_out, qa, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
         return ops_fail(GCM_ERR_HIP, "gcm_advect2d: kernel or copy-back failed");
+    return GCM_OK;
+}
+
+int gcm_pe1d(int n, int nsteps, int half_only, double dt, double dx, const double *const base[4],
+             const double *const stage[4], double *const out[4]) {
+    if (n < 1 || nsteps < 0 || !(dx != 0.0) || !base || !out) return ops_fail(GCM_ERR_ARG, "gcm_pe1d: bad argument");
+    for (int f = 0; f < 4; ++f)
+        if (!base[f] || !out[f] || (half_only && (!stage || !stage[f]))) return ops_fail(GCM_ERR_ARG, "gcm_pe1d: null array");
+    if (gcm_device_count() < 1) return ops_fail(GCM_ERR_NODEVICE, "gcm_pe1d: no HIP device; no CPU fallback");
+    DevBuf mem;
+    double tab[kExnerTabDoubles];
+    build_exner_table(tab);
+    double *dtab = mem.get(kExnerTabDoubles, tab);
+    double *b[4], *s[4], *o[4];
+    for (int f = 0; f < 4; ++f) {
+        b[f] = mem.get(n, base[f]);
+        s[f] = half_only ? mem.get(n, stage[f]) : mem.get(n);
+        o[f] = mem.get(n);
+        if (!b[f] || !s[f] || !o[f] || !dtab) return ops_fail(GCM_ERR_HIP, "gcm_pe1d: device allocation/upload failed");
+    }
+    const dim3 g((n + 255) / 256), blk(256);
+    auto stage_launch = [&](double *const st[4], double *const dst[4]) {
+        Pe1dArgs a{b[0], b[1], b[2], b[3], st[0], st[1], st[2], st[3], dst[0], dst[1], dst[2], dst[3], dtab, n, dt, dx};
+        hipLaunchKernelGGL(pe1d_half_kernel, g, blk, 0, nullptr, a);
+    };
+    if (half_only) {
+        stage_launch(s, o);
+    } else {
+        for (int k = 0; k < nsteps; ++k) {          // matsuno_timestep, no_limits.py:150-152
+            stage_launch(b, s);                     // predictor: stage = base
+            stage_launch(s, o);                     // corrector
+            for (int f = 0; f < 4; ++f) std::swap(b[f], o[f]);      // the new state is the next base
+        }
+        for (int f = 0; f < 4; ++f) o[f] = b[f];
+    }
+    for (int f = 0; f < 4; ++f)
+        if (hipMemcpy(out[f], o[f], (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+            return ops_fail(GCM_ERR_HIP, "gcm_pe1d: kernel or copy-back failed");
     return GCM_OK;
 }
 

@@ -281,6 +281,12 @@ int gcm_pgf2d(int kind, int width, int height, double dt, double dx0, double dx1
  * `u` is ignored by kinds 0 and 1 (may be NULL).                                                 */
 typedef enum { GCM_FL_VAN_LEER = 0, GCM_FL_CALC_R = 1, GCM_FL_DONOR_FLUX = 2, GCM_FL_DONOR_ADVECTION = 3 } gcm_fl_kind;
 int gcm_flux_limiter(int kind, int n, const double *q, const double *u, double dx, double dt, double *out);
+/* The 1-D model of BASELINE configs[0] (no_limits.py:50-152): p, u, theta, q on a periodic line of n
+ * cells, momentum form.  half_only = 1: ONE Euler stage, half_timestep(p,u,t,q, sp,su,st,sq, dt, dx)
+ * (:115-147), base and stage given; half_only = 0: nsteps full Matsuno steps, matsuno_timestep
+ * (:150-152), `stage` ignored.  Arrays are {p, u, t, q}, host float64.                            */
+int gcm_pe1d(int n, int nsteps, int half_only, double dt, double dx, const double *const base[4],
+             const double *const stage[4], double *const out[4]);
 const char *gcm_ops_last_error(void);
 
 /* Timing helper for bench.py: runs nsteps steps bracketed by HIP events on the
