@@ -335,10 +335,10 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
             kiso = None
             launches = 1
             if model == "PE25D":
-                # one Euler stage = five launches (spu filter, pit, geopot, pgf filter, update) on two
+                # one Euler stage = five launches (spu filter, pit2d, geopot, pgf filter, update) on two
                 # streams; the roofline entry is the WHOLE stage: half of the step's algorithmic bytes over
                 # half of the step's device time (HIP events around the timed blocks)
-                kname, kms, launches = ("pe25d stage: pe_spu_filter + pe_pit + pe_geopot + pe_pgf_filter + pe_update_rows"
+                kname, kms, launches = ("pe25d stage: pe_spu_filter + pe_pit2d + pe_geopot + pe_pgf_filter + pe_update_rows"
                                         + (" (+ half of pe_radiation)" if phys else "")), region["ms"] / launches_timed / 2, 2
             elif variant == "fused" and model == "SW2D":
                 # plain shallow water steps in pairs (one launch = two steps): per-step figures
@@ -360,7 +360,8 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
                 if model == "PE25D":                   # sum over the stage's kernels (each once per stage)
                     traffic = sum(v["hbm_bytes_per_launch"] for kk, v in tj.items()
                                   if kk.startswith("gcm::pe_") and "to_device" not in kk and "to_host" not in kk
-                                  and "radiation" not in kk and "energy" not in kk)
+                                  and "radiation" not in kk and "energy" not in kk
+                                  and "colsum" not in kk)          # (colsum: once after set_state, not per stage)
                     if phys:
                         traffic += tj["gcm::pe_radiation_kernel"]["hbm_bytes_per_launch"] / 2.0
                 else:

@@ -758,6 +758,7 @@ static int band_step_pe(gcm_handle *h, double dt) {
 // launches for good; results are identical either way.
 static int band_step_pe_graph(gcm_handle *h, double dt) {
     const int par = pe25d_parity(h->pe);
+    if (!pe25d_step_is_steady(h->pe)) return band_step_pe(h, dt);       // first step after a new state: not a step to record or replay
     if (h->step_graph[par] && h->step_graph_dt[par] == dt) {
         HIPCHK(h, hipGraphLaunch(h->step_graph[par], h->stream));
         pe25d_advance_step(h->pe);

@@ -46,6 +46,9 @@ struct PeArgsT {
     // intermediates
     T *spu, *phi, *pgfu;              // 3-D (phi: even levels only, see rho_of / phi_up)
     T *pit, *pn;                      // 2-D
+    // column sums sum_k dsig[k] u[k], sum_k dsig[k] v[k] of the stage state (own rows; see pe_pit2d_kernel)
+    // and where K4 leaves those of the state it writes (null: not kept)
+    T *scs_u, *scs_v, *ocs_u, *ocs_v;
     T *part;                          // [nseg-1] 2-D slabs: conv summed from the top down to a segment boundary
     // tables (device)
     const T *inv_dxj, *inv_dxh;       // [Hg] reciprocals of geometry.py:136-137
@@ -382,6 +385,82 @@ __global__ __launch_bounds__(256) void pe_pit_kernel(PeArgsT<T> a) {
     }
 }
 
+// ---------------------------------------------------------------- K2b', the 2-D form of pit
+// The filter is linear and iph(sp), jph(sp) do not depend on the level, so
+//   pit = sum_k dsig[k] conv[k] = d_i( filter(iph(sp) U) ) / dx + d_j( jph(sp) V ) / dy,
+//   U = sum_k dsig[k] su[k], V = sum_k dsig[k] sv[k]:
+// one filtered ROW per latitude instead of a second pass over the 3-D spu and sv (the sum is
+// reassociated: pit moves by a few ulp of its largest term, far inside the 1e-10 of the state).
+// K4 leaves U and V of the state it writes (cs_acc per level, k = L-1 .. 0); rows it does not own --
+// a band's ghost rows -- are summed by pe_colsum_kernel from the 3-D winds in the same order with the
+// same fma, so a band and the single domain see the same bits.
+template <typename T>
+__device__ __forceinline__ T cs_acc(T acc, T x, T dsg) { return fma(x, dsg, acc); }
+template <typename T>
+__device__ __forceinline__ T column_sum(const T *col, const T *dsig, int L, int W) {
+    T acc = T(0.0);
+    for (int k = L - 1; k >= 0; --k) acc = cs_acc(acc, col[(long)k * W], dsig[k]);
+    return acc;
+}
+// U, V of the stage state's rows [j0, j1) and [jb0, jb1): the rows no K4 has produced them for (a
+// state that came through gcm_set_state; a band's ghost rows, which the exchange fills)
+template <typename T>
+__global__ __launch_bounds__(256) void pe_colsum_kernel(PeArgsT<T> a) {
+    const Idx ix{a.W, a.H, a.L, a.wrap};
+    const int W = a.W;
+    const int iblocks = (W + 255) / 256;
+    const int jrel = blockIdx.x / iblocks;
+    const int i = (blockIdx.x - jrel * iblocks) * 256 + threadIdx.x;
+    const int na = a.j1 - a.j0;
+    if (i >= W || jrel >= na + (a.jb1 - a.jb0)) return;
+    const int j = jrel < na ? a.j0 + jrel : a.jb0 + (jrel - na);
+    a.scs_u[ix.r2(j) + i] = column_sum(a.su + ix.r3(j) + i, a.dsig, a.L, W);
+    a.scs_v[ix.r2(j) + i] = column_sum(a.sv + ix.r3(j) + i, a.dsig, a.L, W);
+}
+// one workgroup per row j of [j0, j1): pit and p_n = p - pit dt (dynamics.py:38-40,194)
+template <typename T, int MAXR, unsigned MASK = 0>
+__global__ __launch_bounds__(512) void pe_pit2d_kernel(PeArgsT<T> a) {
+    using V = typename Vec2<T>::type;
+    extern __shared__ unsigned char lds_raw[];
+    V *x = (V *)lds_raw;
+    const Idx ix{a.W, a.H, a.L, a.wrap};
+    const int W = a.W;
+    T *fx = (T *)(x + (MAXR > 0 ? 1 : 2) * W);                  // the filtered row, after the transform's workspace
+    const int j = a.j0 + blockIdx.x;
+    const int jg = wrapi(a.row0 + j, a.Hg);
+    const T *sp = a.sp + ix.r2(j);
+    const T *cu = a.scs_u + ix.r2(j);
+    const auto load = [=](int i, int = 0) {
+        const int ie = i + 1 == W ? 0 : i + 1;
+        const T pe = (sp[i] + sp[ie]) * T(0.5);                  // iph(p), dynamics.py:15-17
+        return mkv<V>(cu[i] * pe, T(0.0));
+    };
+    const auto store = [=](int i, V v) { fx[i] = v.x; };
+    if (a.filter && W > 1) {
+        if (MAXR > 0) {
+            filter_rows_composite<MAXR, MASK, T>(x, load, store, a.tw, a.cplan, W, a.smul + (long)jg * (W / 2 + 1));
+        } else {
+            for (int i = threadIdx.x; i < W; i += blockDim.x) x[i] = load(i);
+            __syncthreads();
+            const V *res = filter_rows<T>(x, x + W, a.tw, a.plan, a.smul + (long)jg * (W / 2 + 1));
+            for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, res[i]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, load(i));
+    }
+    __syncthreads();
+    const T inv_dxj = a.inv_dxj[jg], inv_dy = a.inv_dy;
+    const T *spn = a.sp + ix.r2(j - 1), *sps = a.sp + ix.r2(j + 1);
+    const T *cvc = a.scs_v + ix.r2(j), *cvn = a.scs_v + ix.r2(j - 1);
+    for (int i = threadIdx.x; i < W; i += blockDim.x) {
+        const int iw = i == 0 ? W - 1 : i - 1;
+        const T jph_c = (sp[i] + sps[i]) * T(0.5), jph_n = (spn[i] + sp[i]) * T(0.5);  // jph(sp) at j, j-1
+        const T pit = (fx[i] - fx[iw]) * inv_dxj + (cvc[i] * jph_c - cvn[i] * jph_n) * inv_dy;
+        a.pit[ix.r2(j) + i] = pit;
+        a.pn[ix.r2(j) + i] = a.p[ix.r2(j) + i] - pit * a.dt;
+    }
+}
+
 // ---------------------------------------------------------------- K3: pgfu = filter(pgu + phiu)
 // The workgroup of (row, level pair k0 = 2 b, k1 = k0 + 1) rebuilds rho on both levels and phi on
 // the odd one from theta (see rho_of / phi_up); phi[k0] is the anchor pe_geopot_kernel stored.
@@ -400,8 +479,16 @@ __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
     V *x = (V *)lds_raw;
     for (int n = threadIdx.x; n < kExnerTabDoubles; n += blockDim.x) tab[n] = a.exner_tab[n];
     const Idx ix{a.W, a.H, a.L, a.wrap};
-    const int j = a.j0 + blockIdx.x;
-    const int k0 = 2 * blockIdx.y, k1 = k0 + 1;
+    // 1-D grid of 8 x ceil(rows / 8) x pairs workgroups.  Consecutive workgroup ids go to the 8 XCDs
+    // in turn; within an XCD the level pairs of a row follow one another, so that the row's sp and
+    // filter multiplier (read by every pair) come from that XCD's L2 after the first.
+    const int npairs = (a.L + 1) / 2;
+    const int rows_per_xcd = gridDim.x / (8 * npairs);
+    const int l = blockIdx.x / 8;
+    const int jrel = (blockIdx.x % 8) * rows_per_xcd + l / npairs;
+    if (jrel >= a.j1 - a.j0) return;                             // padding (uniform)
+    const int j = a.j0 + jrel;
+    const int k0 = 2 * (l % npairs), k1 = k0 + 1;
     const bool two = k1 < a.L;
     const int W = a.W;
     const int jg = wrapi(a.row0 + j, a.Hg);
@@ -849,6 +936,7 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
     // (face_flux_v), so a segmented march gives the same bits
     T rc_c = T(0.0), rc_s = T(0.0);
     T fu_up = T(0.0), fv_up = T(0.0), ft_up = T(0.0), fq_up = T(0.0);
+    T cs_u = T(0.0), cs_v = T(0.0);                              // sum_k dsig[k] u_n[k], v_n[k] (pe_pit2d_kernel)
     load(q[0], k0);
     if (k_hi < L) {
         const T *part = a.part + (long)seg * a.part_stride;
@@ -974,6 +1062,8 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
         if (pole_edge) v_n *= T(0.0);                               // v_n[:, -1, :] *= 0, dynamics.py:222
         const T t_n = (bt_c * pb_c - (adt + dts) * dt) * inv_pn;
         const T q_n = (bq_c * pb_c - (adq + dqs) * dt) * inv_pn;
+        cs_u = cs_acc(cs_u, u_n, dsg);
+        cs_v = cs_acc(cs_v, v_n, dsg);
         if (store) {
             const long o = (long)j * L * W + kc + i;             // rows to produce are interior: no wrap
             a.ou[o] = u_n;
@@ -999,6 +1089,10 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
         __syncthreads();
         { const int t = bc; bc = bm; bm = bf; bf = t; }
         --k;
+    }
+    if (store && a.ocs_u) {                                      // whole column marched (nseg == 1)
+        a.ocs_u[(long)j * W + i] = cs_u;
+        a.ocs_v[(long)j * W + i] = cs_v;
     }
 }
 
@@ -1196,6 +1290,7 @@ struct PeBufs {
     // state sets: 0/1 ping-pong (cur = set[cur_i]), 2 = star.  [f] p,u,v,t,q; interior pointers
     T *st[3][GCM_NFIELDS] = {};
     T *spu = nullptr, *phi = nullptr, *pgfu = nullptr, *pit = nullptr, *pn = nullptr;
+    T *cs[3][2] = {};                           // per state set: sum_k dsig[k] u[k], sum_k dsig[k] v[k] (2-D)
     T *part = nullptr;                          // (kMaxSeg - 1) slabs like pit
     T *cor_u = nullptr, *cor_v = nullptr;
     T *inv_dxj = nullptr, *inv_dxh = nullptr, *sig = nullptr, *dsig = nullptr, *inv_dsig = nullptr,
@@ -1216,6 +1311,8 @@ struct Pe25d {
     int nseg = 1;                               // level segments of K4, chosen from the band's size
     int upd_rows = 7;                           // rows per workgroup of the row-group K4 (0: one-wave form)
     int cus = 256;
+    bool pit2d = true;                          // pit from the column sums K4 leaves (nseg == 1, row-group K4)
+    bool cs_valid[3] = {false, false, false};   // the state set's column sums belong to its winds
     int pack_set = -1;                          // >= 0: state set gcm_halo_pack reads (step_phase)
     double *stage3 = nullptr;                   // float64 transpose staging, host layout
     double *exner_tab = nullptr;
@@ -1308,6 +1405,16 @@ static FilterKernel<T> pgf_filter_kernel_for(const SuperPlan &P) {
     return pe_pgf_filter_kernel<T, 25>;
 }
 template <typename T>
+static FilterKernel<T> pit2d_kernel_for(const SuperPlan &P) {
+    if (!P.ok) return pe_pit2d_kernel<T, 0>;
+    if (P.mask == kMask1440) return pe_pit2d_kernel<T, 12, kMask1440>;
+    if (P.mask == kMask2880) return pe_pit2d_kernel<T, 16, kMask2880>;
+    if (P.mask == kMask4096) return pe_pit2d_kernel<T, 16, kMask4096>;
+    if (P.maxr <= 12) return pe_pit2d_kernel<T, 12>;
+    if (P.maxr <= 16) return pe_pit2d_kernel<T, 16>;
+    return pe_pit2d_kernel<T, 25>;
+}
+template <typename T>
 static size_t upd_lds_bytes(int R, int L) { return sizeof(T) * ((size_t)3 * (11 * R + 11) * 64 + 2 + 4 * (size_t)L); }
 // looping filter kernels: the complex row + iph(sp) of the row + the row's multiplier
 template <typename T>
@@ -1342,6 +1449,12 @@ static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
         if (!dev_upload<T>(m, &d, nullptr, n2)) return "intermediate";
         *pp = d + (size_t)kGhost * W;
     }
+    for (int st = 0; st < 3; ++st)
+        for (int f = 0; f < 2; ++f) {
+            T *d = nullptr;
+            if (!dev_upload<T>(m, &d, nullptr, n2)) return "intermediate";
+            B.cs[st][f] = d + (size_t)kGhost * W;
+        }
     {
         T *d = nullptr;
         if (!dev_upload<T>(m, &d, nullptr, n2 * (kMaxSeg - 1))) return "intermediate";
@@ -1392,6 +1505,8 @@ static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
                             (int)filter_lds_bytes<T>(m)) != hipSuccess ||
         hipFuncSetAttribute((const void *)pgf_filter_kernel_for<T>(m->cplan), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)filter_lds_bytes<T>(m)) != hipSuccess ||
+        hipFuncSetAttribute((const void *)pit2d_kernel_for<T>(m->cplan), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(filter_lds_bytes<T>(m) + sizeof(T) * (size_t)W)) != hipSuccess ||
         hipFuncSetAttribute((const void *)pe_geopot_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(L * kColThreads * sizeof(T))) != hipSuccess ||
         hipFuncSetAttribute((const void *)pe_radiation_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1537,13 +1652,19 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
         const double rounds = (double)((W + kUpdCols - 1) / kUpdCols) * m->H / (8.0 * cus);
         long want = (long)std::ceil(1.5 / std::max(rounds, 1e-3));
         m->upd_rows = m->H <= 256 ? 3 : 7;
-        if (const char *e = getenv("GCM_PE_LEVEL_SEGMENTS")) want = atoi(e);
+        bool forced = false;
+        if (const char *e = getenv("GCM_PE_LEVEL_SEGMENTS")) { want = atoi(e); forced = true; }
+        if (const char *e = getenv("GCM_PE_PIT2D")) m->pit2d = atoi(e) != 0;      // 0: pit from the 3-D fields (pe_pit_kernel)
         if (const char *e = getenv("GCM_PE_UPDATE_ROWS")) {      // 0: the one-wave update kernel; 3, 7: rows per group
             const int v = atoi(e);
             m->upd_rows = (v == 0 || v == 3 || v == 7) ? v : 7;
         }
         const int cap = std::min(kMaxSeg, std::max(1, L / 4));
         m->nseg = (int)std::max(1L, std::min((long)cap, want));
+        // the row-group K4 fills the chip with whole columns (a 90-row band: 2 % slower than in two
+        // segments) and then leaves the column sums pit needs: segments only on request, or for the
+        // one-wave kernel
+        if (m->upd_rows > 0 && !forced) m->nseg = 1;
     }
     if (const char *what = m->f32 ? alloc_all<float>(m, cfg) : alloc_all<double>(m, cfg)) return bad(what);
     if (!dev_upload<double>(m, &m->stage3, nullptr, (size_t)m->H * W * L)) return bad("staging");
@@ -1616,6 +1737,7 @@ int pe25d_set(Pe25d *m, bool star, const double *p, const double *u, const doubl
               const double *t, const double *q, hipStream_t s, std::string *err) {
     const double *in[GCM_NFIELDS] = {p, u, v, t, q};
     int rc = xfer(m, star ? 2 : m->cur_i, true, in, nullptr, s, err);
+    if (u || v) m->cs_valid[star ? 2 : m->cur_i] = false;
     if (rc == GCM_OK) m->star_valid = star;
     return rc;
 }
@@ -1642,6 +1764,8 @@ static PeArgsT<T> make_args(Pe25d *m, int stage_set, int out_set, double dt) {
     a.op = O[GCM_P]; a.ou = O[GCM_U]; a.ov = O[GCM_V]; a.ot = O[GCM_T]; a.oq = O[GCM_Q];
     a.spu = Bf.spu; a.phi = Bf.phi; a.pgfu = Bf.pgfu;
     a.pit = Bf.pit; a.pn = Bf.pn;
+    a.scs_u = Bf.cs[stage_set][0]; a.scs_v = Bf.cs[stage_set][1];
+    a.ocs_u = a.ocs_v = nullptr;
     a.part = Bf.part;
     a.part_stride = (long)rows_alloc(m) * m->W;
     a.nseg = m->nseg;
@@ -1678,6 +1802,12 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
     const size_t lds = filter_lds_bytes<T>(m);
     const int fft_threads = m->cplan.ok ? m->cplan.threads : kFftThreads;
     const int pairs = (L + 1) / 2;
+    // pit from the 2-D column sums (pe_pit2d_kernel) where K4 marches whole columns and can leave them
+    const bool p2 = m->pit2d && a.nseg == 1 && m->upd_rows > 0;
+    if (p2) {
+        a.ocs_u = bufs<T>(m).cs[out_set][0];
+        a.ocs_v = bufs<T>(m).cs[out_set][1];
+    }
     if (mode != 2) {
         // two independent chains: K1 -> K2b (mass flux, pit) on the caller's stream, K2a -> K3
         // (geopotential, filtered pressure-gradient force) on the handle's second stream.  The FFT
@@ -1708,7 +1838,25 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         } else {
             hipLaunchKernelGGL(spu_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, s, a);
         }
-        {
+        if (p2) {
+            // rows whose sums no K4 left: all of a freshly set state, else a band's two ghost rows
+            // next to its own (pit of row j takes V of row j - 1; the intermediates extend to row j1)
+            PeArgsT<T> c = a;
+            if (!m->cs_valid[stage_set]) {
+                c.j0 = m->wrap ? 0 : -1;
+                c.j1 = m->H + ext;
+                c.jb0 = c.jb1 = 0;
+                m->cs_valid[stage_set] = true;
+            } else {
+                c.j0 = -1; c.j1 = 0;
+                c.jb0 = m->H; c.jb1 = m->H + 1;
+            }
+            if (!m->wrap || c.j1 - c.j0 > 1) {
+                const int rows = (c.j1 - c.j0) + (c.jb1 - c.jb0);
+                hipLaunchKernelGGL(pe_colsum_kernel<T>, dim3((unsigned)((W + 255) / 256) * rows), dim3(256), 0, s, c);
+            }
+            hipLaunchKernelGGL(pit2d_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0), dim3(fft_threads), lds + sizeof(T) * (size_t)W, s, a);
+        } else {
             const long tiles = (long)((W + 255) / 256) * (a.j1 - a.j0);
             hipLaunchKernelGGL(pe_pit_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, s, a);
         }
@@ -1716,7 +1864,7 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         a.j1 = j1;
         // (a looping form of this filter, as K1's, was built and is 25 % SLOWER: its requests and the
         // per-column thermodynamics push it to 187 VGPRs, two waves per SIMD instead of four)
-        hipLaunchKernelGGL(pgf_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, s2, a);
+        hipLaunchKernelGGL(pgf_filter_kernel_for<T>(m->cplan), dim3((unsigned)(8 * ((a.j1 - a.j0 + 7) / 8) * pairs)), dim3(fft_threads), lds, s2, a);
         if (m->aux) {
             (void)hipEventRecord(m->ev_join, m->aux);
             (void)hipStreamWaitEvent(s, m->ev_join, 0);
@@ -1746,6 +1894,7 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         const long tiles = (long)((W + kUpdThreads - 1) / kUpdThreads) * rows * a.nseg;
         hipLaunchKernelGGL(pe_update_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kUpdThreads), 0, st, a);
     };
+    m->cs_valid[out_set] = p2;                   // (modes 1 + 2 together cover the rows)
     const bool split = mode != 0 && (j1 - j0) > 2 * kGhost;
     if (mode == 0) {
         tick(m, s);
@@ -1907,9 +2056,17 @@ int pe25d_set_halo_buffers(Pe25d *m, void *north, void *south, hipStream_t s, st
 // host-side step state (which state set is current, ...): gcm_band_run replays a captured step as a
 // hipGraph, which runs none of the host code that advances this state
 void pe25d_host_state(Pe25d *m, bool save, int st[4]) {
-    if (save) { st[0] = m->cur_i; st[1] = m->star_valid; st[2] = m->pack_set; st[3] = m->edges_pending; }
-    else { m->cur_i = st[0]; m->star_valid = st[1] != 0; m->pack_set = st[2]; m->edges_pending = st[3] != 0; }
+    if (save) {
+        st[0] = m->cur_i; st[1] = m->star_valid; st[2] = m->pack_set;
+        st[3] = (m->edges_pending ? 1 : 0) | (m->cs_valid[0] ? 2 : 0) | (m->cs_valid[1] ? 4 : 0) | (m->cs_valid[2] ? 8 : 0);
+    } else {
+        m->cur_i = st[0]; m->star_valid = st[1] != 0; m->pack_set = st[2]; m->edges_pending = (st[3] & 1) != 0;
+        for (int n = 0; n < 3; ++n) m->cs_valid[n] = (st[3] & (2 << n)) != 0;
+    }
 }
+// a step recorded now replays correctly later only if it does not contain the one-off column sums
+// of a freshly set state (see half_t)
+bool pe25d_step_is_steady(const Pe25d *m) { return !m->pit2d || m->nseg != 1 || m->upd_rows == 0 || m->cs_valid[m->cur_i]; }
 int pe25d_parity(const Pe25d *m) { return m->cur_i; }
 void pe25d_advance_step(Pe25d *m) {          // what one full band step (phases 0..3) leaves behind
     m->cur_i = 1 - m->cur_i;

@@ -326,8 +326,9 @@ def test_grey_radiation_fp32_handle(g):
 
 @pytest.mark.parametrize("hwl", [(12, 20, 9), (6, 16, 24), (5, 12, 5)])
 def test_level_segments_do_not_change_results(g, hwl, monkeypatch):
-    """the update kernel may march a column in 2-4 level segments (short latitude bands); the
-    partial sums it then starts from are bit-identical to the unsplit march"""
+    """the update kernel may march a column in 2-4 level segments (GCM_PE_LEVEL_SEGMENTS; pit then
+    comes from the 3-D fields, pe_pit_kernel); the partial sums it then starts from are bit-identical
+    to the unsplit march on the same pit"""
     from gcmiipy_amd import geometry
     H, W, L = hwl
     rng = np.random.default_rng(11)
@@ -338,6 +339,7 @@ def test_level_segments_do_not_change_results(g, hwl, monkeypatch):
     t = (300 + rng.standard_normal((L, H, W))) * ((1e5 / (p * geom.sig + geom.ptop)) ** (287.0 / 1004.0))
     q = 3e-6 * (1 + 0.1 * rng.random((L, H, W)))
     res = {}
+    monkeypatch.setenv("GCM_PE_PIT2D", "0")
     for nseg in (1, 2, 3, 4):
         monkeypatch.setenv("GCM_PE_LEVEL_SEGMENTS", str(nseg))
         c = g.Core(g._lib.PE25D, W, H, L, geom=geom, coriolis=(nseg > 0 and H == 12))
@@ -348,6 +350,42 @@ def test_level_segments_do_not_change_results(g, hwl, monkeypatch):
     for nseg in (2, 3, 4):
         for a, b in zip(res[nseg], res[1]):
             assert np.array_equal(a, b), nseg
+
+
+@pytest.mark.parametrize("hwl", [(12, 20, 9), (6, 16, 24), (36, 1440, 5)])
+def test_pit_from_column_sums_vs_3d_form(g, hwl, monkeypatch):
+    """pit = sum_k dsig conv[k] is evaluated from the 2-D column sums of the winds (pe_pit2d_kernel: the
+    filter is linear, so one filtered row per latitude; the default) or level by level from the 3-D
+    fields (pe_pit_kernel, GCM_PE_PIT2D=0; the reference's order, dynamics.py:38-40).  The sum is
+    reassociated, nothing else: both within 1e-13 of each other after 3 steps, and the default within
+    TOL of the oracle."""
+    from gcmiipy_amd import geometry
+    from oracle import dynamics as od, geometry as ogeo
+    H, W, L = hwl
+    rng = np.random.default_rng(12)
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    p = 1e5 + 10 * rng.standard_normal((H, W))
+    u, v = rng.standard_normal((L, H, W)), rng.standard_normal((L, H, W))
+    v[:, -1, :] = 0
+    t = (300 + rng.standard_normal((L, H, W))) * ((1e5 / (p * geom.sig + geom.ptop)) ** (287.0 / 1004.0))
+    q = 3e-6 * (1 + 0.1 * rng.random((L, H, W)))
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GCM_PE_PIT2D", flag)
+        c = g.Core(g._lib.PE25D, W, H, L, geom=geom)
+        c.set_state(p, u, v, t, q)
+        c.step(3, 120.0)
+        res[flag] = c.get_state()
+        c.close()
+    for a, b in zip(res["1"], res["0"]):
+        assert rel_err(a, b) < 1e-13
+    if W <= 64:
+        st = (p, u, v, t, q)
+        og = ogeo.gen_geometry(H, W, L, sig_func=ogeo.manabe_sig)
+        for _ in range(3):
+            st = od.matsuno_timestep(*st, 120.0, og)
+        for a, b in zip(res["1"], st):
+            assert rel_err(a, b) < TOL
 
 
 def test_full_size_properties_c4(g):
