@@ -891,6 +891,8 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
     const int jg_row = wrapi(a.row0 + j, a.Hg);
     const T inv_dxj = a.inv_dxj[jg_row], inv_dxh = a.inv_dxh[jg_row], inv_dy = a.inv_dy, dt = a.dt;
     const T inv_dxj_s = a.inv_dxj[wrapi(a.row0 + j + 1, a.Hg)];
+    const T q_dxj = T(0.25) * inv_dxj, q_dxh = T(0.25) * inv_dxh, q_dy = T(0.25) * inv_dy;
+    const T h_dxj = T(0.5) * inv_dxj, h_dy = T(0.5) * inv_dy;
     const long rc = ix.r3(j);
     const T *spr = a.sp;
     const long p_n = ix.r2(j - 1), p_c = ix.r2(j), p_s = ix.r2(j + 1), p_ss = ix.r2(j + 2);
@@ -913,11 +915,29 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
 
     // own-row requests of one level: su, sv, st, sq, spu, phi anchor, pgfu, base u, v, t, q
     T q[2][11];
+    // (the level's offset is wave-uniform: the request is scalar base + ONE 32-bit byte offset per lane,
+    // the addressing mode that needs no vector arithmetic)
+    const unsigned ob = (unsigned)i * (unsigned)sizeof(T);
+    // (the base goes through an opaque scalar register pair: left visible, the compiler reassociates
+    // it into eleven loop-invariant per-lane 64-bit addresses plus a scalar level offset -- 22 VGPRs
+    // and a 64-bit vector add per request)
+    const auto sbase = [](const T *p) {
+        unsigned long long v = (unsigned long long)p;
+        unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+        asm volatile("" : "+s"(lo), "+s"(hi));
+        return (__attribute__((address_space(1))) char *)(((unsigned long long)hi << 32) | lo);      // global, not flat
+    };
     const auto load = [&](T (&d)[11], int k) {
-        const long o = rc + (long)k * W + i;
-        d[0] = a.su[o]; d[1] = a.sv[o]; d[2] = a.st[o]; d[3] = a.sq[o]; d[4] = a.spu[o]; d[6] = a.pgfu[o];
-        d[5] = a.phi[rc + (long)(k & ~1) * W + i];           // the anchor at or below k (odd k: unused, and a cache hit)
-        if (!same) { d[7] = a.u[o]; d[8] = a.v[o]; d[9] = a.t[o]; d[10] = a.q[o]; }
+        // (the lane offset is made opaque once per level, so that its zero extension stays next to the
+        // requests and they take the scalar-base + 32-bit-offset form)
+        unsigned ol = ob;
+        asm volatile("" : "+v"(ol));
+        const auto at = [ol, sbase](const T *base) { return *(const __attribute__((address_space(1))) T *)(sbase(base) + ol); };
+        const long o = rc + (long)k * W;
+        d[0] = at(a.su + o); d[1] = at(a.sv + o); d[2] = at(a.st + o); d[3] = at(a.sq + o);
+        d[4] = at(a.spu + o); d[6] = at(a.pgfu + o);
+        d[5] = at(a.phi + (rc + (long)(k & ~1) * W));        // the anchor at or below k (odd k: unused, and a cache hit)
+        if (!same) { d[7] = at(a.u + o); d[8] = at(a.v + o); d[9] = at(a.t + o); d[10] = at(a.q + o); }
     };
     const auto put = [&](const T (&d)[11], int buf) {
         T *t = t0 + buf * kBuf;
@@ -964,13 +984,15 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
         const auto own = [&](const T *t, int f) { return t[(TL::kMain + f * (R + 2) + 1 + r) * 64]; };
         const auto nrow = [&](const T *t, int f) { return t + (TL::kMain + f * (R + 2) + r) * 64; };
         const auto srow = [&](const T *t, int f) { return t + (TL::kMain + f * (R + 2) + 2 + r) * 64; };
+        const auto orow = [&](const T *t, int f) { return t + (TL::kMain + f * (R + 2) + 1 + r) * 64; };
         const T su_c = own(tc, 0), sv_c = own(tc, 1), st_c = own(tc, 2), sq_c = own(tc, 3), spu_c = own(tc, 4);
-        // ---- neighbours: own row by lane shifts, rows j-1 / j+1 from the tile
-        const T su_w = from_west(su_c), su_e = from_east(su_c);
-        const T sv_w = from_west(sv_c), sv_e = from_east(sv_c);
-        const T spu_w = from_west(spu_c), spu_e = from_east(spu_c);
-        const T st_w = from_west(st_c), st_e = from_east(st_c);
-        const T sq_w = from_west(sq_c), sq_e = from_east(sq_c);
+        // ---- neighbours: columns i-1 / i+1 of the own row and rows j-1 / j+1 from the tile (the edge
+        //      lanes read a word of the neighbouring slot: they feed nothing that is stored)
+        const T su_w = orow(tc, 0)[-1], su_e = orow(tc, 0)[1];
+        const T sv_w = orow(tc, 1)[-1], sv_e = orow(tc, 1)[1];
+        const T spu_w = orow(tc, 4)[-1], spu_e = orow(tc, 4)[1];
+        const T st_w = orow(tc, 2)[-1], st_e = orow(tc, 2)[1];
+        const T sq_w = orow(tc, 3)[-1], sq_e = orow(tc, 3)[1];
         const T su_n = *nrow(tc, 0), sv_n = *nrow(tc, 1), sv_ne = nrow(tc, 1)[1], st_n = *nrow(tc, 2), sq_n = *nrow(tc, 3);
         const T su_s = *srow(tc, 0), sv_s = *srow(tc, 1), st_sl = *srow(tc, 2), sq_s = *srow(tc, 3);
         const T spu_s = *srow(tc, 4), spu_sw = srow(tc, 4)[-1];
@@ -988,14 +1010,17 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
         }
         const T sd_e = from_east(sd_c);
         // ---- advec_m_pu, dynamics.py:55-108
-        const T puum = ((su_c + su_w) * T(0.5)) * ((spu_c + spu_w) * T(0.5));
-        const T puup = ((su_e + su_c) * T(0.5)) * ((spu_e + spu_c) * T(0.5));
-        const T puvp = ((spv_c + spv_e) * T(0.5)) * ((su_c + su_s) * T(0.5));
-        const T puvm = ((spv_n + spv_ne) * T(0.5)) * ((su_n + su_c) * T(0.5));
-        const T pvvm = ((sv_c + sv_n) * T(0.5)) * ((spv_c + spv_n) * T(0.5));
-        const T pvvp = ((sv_s + sv_c) * T(0.5)) * ((spv_s + spv_c) * T(0.5));
-        const T pvup = ((sv_c + sv_e) * T(0.5)) * ((spu_c + spu_s) * T(0.5));
-        const T pvum = ((sv_w + sv_c) * T(0.5)) * ((spu_w + spu_sw) * T(0.5));
+        // ---- advec_m_pu, dynamics.py:55-108.  Every product there is a product of two averages,
+        //      ((a + b)/2) ((c + d)/2): the quarters are taken out of the sums and folded into the grid
+        //      factors (q_dx = 1/(4 dx)) -- scaling by a power of two commutes with every rounding
+        const T puum = (su_c + su_w) * (spu_c + spu_w);
+        const T puup = (su_e + su_c) * (spu_e + spu_c);
+        const T puvp = (spv_c + spv_e) * (su_c + su_s);
+        const T puvm = (spv_n + spv_ne) * (su_n + su_c);
+        const T pvvm = (sv_c + sv_n) * (spv_c + spv_n);
+        const T pvvp = (sv_s + sv_c) * (spv_s + spv_c);
+        const T pvup = (sv_c + sv_e) * (spu_c + spu_s);
+        const T pvum = (sv_w + sv_c) * (spu_w + spu_sw);
         T cor_u = T(0.0), cor_v = T(0.0);                         // the reference adds a literal 0
         if (coriolis) {                                          // dynamics.py:83-92
             const T pu_at_pv = (((spu_c + spu_s) * T(0.5)) + ((spu_w + spu_sw) * T(0.5))) * T(0.5);    // imh(jph(pu))
@@ -1003,13 +1028,13 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
             cor_u = cp_u * -pv_at_pu;
             cor_v = cp_v * pu_at_pv;
         }
-        const T dut = (puum - puup) * inv_dxj + (puvm - puvp) * inv_dy + cor_u;
-        const T dvt = (pvvm - pvvp) * inv_dy + (pvum - pvup) * inv_dxh + cor_v;
-        // ---- advec_t for t and q, dynamics.py:174-181
-        const T adt = (spu_c * ((st_c + st_e) * T(0.5)) - spu_w * ((st_w + st_c) * T(0.5))) * inv_dxj +
-                      (spv_c * ((st_c + st_sl) * T(0.5)) - spv_n * ((st_n + st_c) * T(0.5))) * inv_dy;
-        const T adq = (spu_c * ((sq_c + sq_e) * T(0.5)) - spu_w * ((sq_w + sq_c) * T(0.5))) * inv_dxj +
-                      (spv_c * ((sq_c + sq_s) * T(0.5)) - spv_n * ((sq_n + sq_c) * T(0.5))) * inv_dy;
+        const T dut = (puum - puup) * q_dxj + (puvm - puvp) * q_dy + cor_u;
+        const T dvt = (pvvm - pvvp) * q_dy + (pvum - pvup) * q_dxh + cor_v;
+        // ---- advec_t for t and q, dynamics.py:174-181 (flux times ONE average: halves folded, h_dx = 1/(2 dx))
+        const T adt = (spu_c * (st_c + st_e) - spu_w * (st_w + st_c)) * h_dxj +
+                      (spv_c * (st_c + st_sl) - spv_n * (st_n + st_c)) * h_dy;
+        const T adq = (spu_c * (sq_c + sq_e) - spu_w * (sq_w + sq_c)) * h_dxj +
+                      (spv_c * (sq_c + sq_s) - spv_n * (sq_n + sq_c)) * h_dy;
         // ---- the level below (k-1), from its tile: vertical fluxes and the anchor step.  At k == 0 the
         //      lower face carries sd[0] = 0: any finite value serves
         T su_m = su_c, sv_m = sv_c, st_m = st_c, sq_m = sq_c;
@@ -1036,7 +1061,8 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
         }
         const T rho_c = rho_of(sp_c * sg + ptop, st_c, ex_c), rho_s = rho_of(sp_s * sg + ptop, st_s, ex_s);
         const T phiv = jph_c * ((phi_s - phi_c) * inv_dy);
-        const T pgv = ((sg * sp_c + sg * sp_s) * T(0.5)) * rcp((rho_c + rho_s) * T(0.5)) * ((sp_s - sp_c) * inv_dy);
+        // jph(sig p) / jph(rho): the two halves cancel exactly
+        const T pgv = (sg * sp_c + sg * sp_s) * rcp(rho_c + rho_s) * ((sp_s - sp_c) * inv_dy);
         // ---- vertical advection, dynamics.py:49-52 with iph(sd), jph(sd), sd
         const T inv_ds = lv_inv_dsig[k];
         const T fu = face_flux_v(su_c, su_m, (sd_c + sd_e) * T(0.5)), fv = face_flux_v(sv_c, sv_m, (sd_c + sd_s) * T(0.5));
@@ -1065,11 +1091,13 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
         cs_u = cs_acc(cs_u, u_n, dsg);
         cs_v = cs_acc(cs_v, v_n, dsg);
         if (store) {
-            const long o = (long)j * L * W + kc + i;             // rows to produce are interior: no wrap
-            a.ou[o] = u_n;
-            a.ov[o] = v_n;
-            a.ot[o] = t_n;
-            a.oq[o] = q_n;
+            const long o = (long)j * L * W + kc;                 // rows to produce are interior: no wrap
+            unsigned ol = ob;
+            asm volatile("" : "+v"(ol));
+            *(__attribute__((address_space(1))) T *)(sbase(a.ou + o) + ol) = u_n;
+            *(__attribute__((address_space(1))) T *)(sbase(a.ov + o) + ol) = v_n;
+            *(__attribute__((address_space(1))) T *)(sbase(a.ot + o) + ol) = t_n;
+            *(__attribute__((address_space(1))) T *)(sbase(a.oq + o) + ol) = q_n;
         }
     };
     // two request sets that swap BY NAME (loop unrolled by two): a register copy of a value still in
@@ -1864,6 +1892,8 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         a.j1 = j1;
         // (a looping form of this filter, as K1's, was built and is 25 % SLOWER: its requests and the
         // per-column thermodynamics push it to 187 VGPRs, two waves per SIMD instead of four)
+        // (launched with whole waves -- 192 threads for the 144 butterflies of a 1440 row, so that the
+        // per-column thermodynamics ahead of the transform fills its lanes -- it takes the same time)
         hipLaunchKernelGGL(pgf_filter_kernel_for<T>(m->cplan), dim3((unsigned)(8 * ((a.j1 - a.j0 + 7) / 8) * pairs)), dim3(fft_threads), lds, s2, a);
         if (m->aux) {
             (void)hipEventRecord(m->ev_join, m->aux);
