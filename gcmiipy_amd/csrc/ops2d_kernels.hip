@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void momentum_kernel(double *m0, double *m1, c
 }
 
 // kind: 0 pgf_c_grid_axis gradients only, 1 pgf_c_grid (needs t), 2 pgf_templess, 3 pressure_at_edge
+// (o0 alone = pressure_at_edge_one_d), 4 gradient (centred), 5 pressure_gradient (needs t), 6 pgf_one_d
 __global__ __launch_bounds__(256) void pgf_kernel(double *o0, double *o1, const double *p, const double *t,
                                                  const double *etab, int kind, int W, int H, double dt,
                                                  double dx0, double dx1) {
@@ -91,8 +92,22 @@ __global__ __launch_bounds__(256) void pgf_kernel(double *o0, double *o1, const 
     } else if (kind == 2) {                                           // two_d.py:248-261
         const double d0 = ((ps + pc) * 0.5) / (kRd * 273.16), d1 = ((pe + pc) * 0.5) / (kRd * 273.16);
         o0[o] = g0 * dt / d0; o1[o] = g1 * dt / d1;
-    } else {                                                          // two_d.py:264-268
+    } else if (kind == 3) {                                           // two_d.py:264-274
         o0[o] = (ps + pc) * 0.5; o1[o] = (pe + pc) * 0.5;
+    } else if (kind == 6) {                                           // pgf_one_d, two_d.py:295-303:
+        // the edge density is ALWAYS taken along axis 0 (pressure_at_edge_one_d), whatever `axis`
+        const double d0 = ((ps + pc) * 0.5) / (kRd * 273.16);
+        o0[o] = g0 * dt / d0; o1[o] = g1 * dt / d0;
+    } else {                                                          // centred gradient, two_d.py:74-77
+        const double pn = p[at2(j - 1, i, H, W)], pw = p[at2(j, i - 1, H, W)];
+        const double c0 = (ps - pn) / (2 * dx0), c1 = (pe - pw) / (2 * dx1);
+        if (kind == 4) {
+            o0[o] = c0; o1[o] = c1;
+        } else {                                                      // pressure_gradient, two_d.py:80-100
+            const double true_t = t[o] * exner(pc, tab);
+            const double rho = pc / (kRd * true_t);
+            o0[o] = c0 / rho * dt; o1[o] = c1 / rho * dt;
+        }
     }
 }
 
@@ -300,7 +315,7 @@ int gcm_flux_limiter(int kind, int n, const double *q, const double *u, double d
 
 int gcm_pgf2d(int kind, int width, int height, double dt, double dx0, double dx1, const double *p,
               const double *t, double *out2) {
-    if (!p || !out2 || width < 1 || height < 1 || kind < 0 || kind > 3 || (kind == 1 && !t))
+    if (!p || !out2 || width < 1 || height < 1 || kind < 0 || kind > 6 || ((kind == 1 || kind == 5) && !t))
         return ops_fail(GCM_ERR_ARG, "gcm_pgf2d: bad argument");
     if (gcm_device_count() < 1) return ops_fail(GCM_ERR_NODEVICE, "gcm_pgf2d: no HIP device; no CPU fallback");
     const size_t n = (size_t)width * height;

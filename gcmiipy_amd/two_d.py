@@ -88,6 +88,8 @@ def _pgf(kind, dt, spatial_change, p, t=None):
     pm = as_f64(pm, name="p")
     if pm.ndim != 2:
         raise ValueError("p must be 2-D")
+    if len(spatial_change) != 2:
+        raise ValueError("spatial_change must have one entry per axis")
     tm = None if tm is None else as_f64(tm, pm.shape, "t")
     out = np.empty((2,) + pm.shape)
     _ops_check(lib.gcm_pgf2d(kind, pm.shape[1], pm.shape[0], scalar(dt), scalar(spatial_change[0]),
@@ -109,6 +111,38 @@ def pgf_templess(dt, spatial_change, p):                                # two_d.
 
 def pressure_at_edge(p):                                                # two_d.py:264-268
     return _pgf(3, 0.0, (1.0, 1.0), p)
+
+
+def _line_or_plane(p):
+    """the *_one_d helpers take 1-D lines or 2-D arrays (axis 0 is the one they roll)"""
+    pm = as_f64(strip(p)[0], name="p")
+    if pm.ndim == 1:
+        return pm.reshape(-1, 1), True
+    if pm.ndim != 2:
+        raise ValueError("p must be 1-D or 2-D")
+    return pm, False
+
+
+def pressure_at_edge_one_d(p):                                          # two_d.py:271-274
+    pm, line = _line_or_plane(p)
+    out = _pgf(3, 0.0, (1.0, 1.0), pm)[0]
+    return out[:, 0] if line else out
+
+
+def pgf_one_d(dt, dx, p, axis=0):                                       # two_d.py:295-303
+    pm, line = _line_or_plane(p)
+    if axis not in ((0,) if line else (0, 1)):
+        raise ValueError("axis out of range")
+    out = _pgf(6, dt, (dx, dx), pm)[axis]
+    return out[:, 0] if line else out
+
+
+def gradient(p, spatial_change, axis):                                  # two_d.py:74-77
+    return _pgf(4, 0.0, spatial_change, p)[axis]
+
+
+def pressure_gradient(dt, spatial_change, p, t):                        # two_d.py:80-100
+    return _pgf(5, dt, spatial_change, p, t)
 
 
 def run_2d_with_ft(initial_conditions, ft, steps=400, display_key="q", variation_key="q",

@@ -268,7 +268,11 @@ typedef enum {
 int gcm_advect2d(int scheme, int axes, int finite, int width, int height, int nsteps, double dt,
                  double dx0, double dx1, const double *V, const double *q_in, double *q_out);
 /* kind 0: pgf_c_grid_axis gradients (two_d.py:210-220); 1: pgf_c_grid (needs t, :223-245);
- * 2: pgf_templess (:248-261); 3: pressure_at_edge (:264-268).  out2 is [2][H][W].           */
+ * 2: pgf_templess (:248-261); 3: pressure_at_edge (:264-268; out2[0] alone is
+ * pressure_at_edge_one_d, :271-274); 4: gradient, centred (:74-77); 5: pressure_gradient (needs t,
+ * :80-100); 6: pgf_one_d along axis 0 in out2[0] and along axis 1 in out2[1] (:295-303; the edge
+ * density is taken along axis 0 for either, as the reference does).  out2 is [2][H][W]; a 1-D array
+ * of n cells is height n, width 1.                                                          */
 int gcm_pgf2d(int kind, int width, int height, double dt, double dx0, double dx1, const double *p,
               const double *t, double *out2);
 /* flux_limiter.py on 1-D arrays of n cells (host arrays in/out; ip/im = np.roll by -1/+1,

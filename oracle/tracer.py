@@ -137,6 +137,19 @@ def pgf_one_d(dt, dx, p, axis=0):
     return pressure_gradient * dt / d_edge
 
 
+def gradient(p, spatial_change, axis):
+    """two_d.py:74-77 (centred)."""
+    return (np.roll(p, -1, axis) - np.roll(p, 1, axis)) / (2 * spatial_change[axis])
+
+
+def pressure_gradient(dt, spatial_change, p, t):
+    """two_d.py:80-100."""
+    grad = np.stack([gradient(p, spatial_change, 0), gradient(p, spatial_change, 1)])
+    true_t = t / (P0 / p) ** kappa
+    rho = p / (Rd * true_t)
+    return grad / rho * dt
+
+
 # ---- flux_limiter.py (1-D) ------------------------------------------------
 def van_leer(r):
     """flux_limiter.py:10-11."""

@@ -185,6 +185,11 @@ def g4_tracer():
     out["p_edge_1d"] = m(two_d.pressure_at_edge_one_d(p))
     out["adv_mom"] = m(two_d.advect_with_momentum(DT, SC, V, p))
     out["pgf_one_d"] = m(two_d.pgf_one_d(DT, SC[0], p))
+    out["pgf_one_d_axis1"] = m(two_d.pgf_one_d(DT, SC[1], p, 1))
+    out["pgf_one_d_line"] = m(two_d.pgf_one_d(DT, SC[0], p[:, 0]))
+    for ax in (0, 1):
+        out["gradient%d" % ax] = m(two_d.gradient(p, SC, ax))
+    out["pressure_gradient"] = m(two_d.pressure_gradient(DT, SC, p, t))
     # 1-D limiter pieces
     q1 = rng.random(16)
     q1[3] = q1[4] = q1[5]          # exact-zero denominators for calc_r

@@ -108,6 +108,11 @@ def test_g4_tracer():
     same(tracer.pressure_at_edge_one_d(p), d["p_edge_1d"])
     same(tracer.advect_with_momentum(dt, sc, V, p), d["adv_mom"])
     same(tracer.pgf_one_d(dt, sc[0], p), d["pgf_one_d"])
+    same(tracer.pgf_one_d(dt, sc[1], p, 1), d["pgf_one_d_axis1"])
+    same(tracer.pgf_one_d(dt, sc[0], p[:, 0]), d["pgf_one_d_line"])
+    for ax in (0, 1):
+        same(tracer.gradient(p, sc, ax), d["gradient%d" % ax])
+    same(tracer.pressure_gradient(dt, sc, p, t), d["pressure_gradient"])
     q1, u1 = d["q1"], d["u1"]
     r = tracer.calc_r(q1)
     same(r, d["r1"])

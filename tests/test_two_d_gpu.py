@@ -30,6 +30,18 @@ def test_two_d_operators_vs_golden():
     assert rel_err(two_d.pgf_c_grid(dt, sc, p, t), d["pgf_c_grid"]) < TOL
     assert rel_err(two_d.pgf_templess(dt, sc, p), d["pgf_templess"]) < TOL
     assert rel_err(two_d.pressure_at_edge(p), d["p_edge"]) < TOL
+    assert rel_err(two_d.pressure_at_edge_one_d(p), d["p_edge_1d"]) < TOL
+    assert rel_err(two_d.pressure_at_edge_one_d(p[:, 3]), d["p_edge_1d"][:, 3]) < TOL      # a 1-D line
+    assert rel_err(two_d.pgf_one_d(dt, sc[0], p), d["pgf_one_d"]) < TOL
+    assert rel_err(two_d.pgf_one_d(dt, sc[1], p, 1), d["pgf_one_d_axis1"]) < TOL
+    assert rel_err(two_d.pgf_one_d(dt, sc[0], p[:, 0]), d["pgf_one_d_line"]) < TOL
+    for ax in (0, 1):
+        assert rel_err(two_d.gradient(p, sc, ax), d["gradient%d" % ax]) < TOL
+    assert rel_err(two_d.pressure_gradient(dt, sc, p, t), d["pressure_gradient"]) < TOL
+    with pytest.raises(ValueError):
+        two_d.pgf_one_d(dt, sc[0], p[:, 0], 1)
+    with pytest.raises(ValueError):
+        two_d.pressure_gradient(dt, sc, p, None)
     assert rel_err(two_d.advect_with_momentum(dt, sc, V, p), d["adv_mom"]) < TOL
 
 
