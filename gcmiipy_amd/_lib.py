@@ -67,6 +67,7 @@ SYMBOLS = {
     "gcm_energy": (C.c_int, [_H, _dp, C.c_int, _dp]),
     "gcm_stats": (C.c_int, [_H, _dp, C.c_int, _dp]),
     "gcm_flux_limiter": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
+    "gcm_polar_filter": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
     "gcm_set_ground": (C.c_int, [_H, C.c_void_p]),
     "gcm_get_ground": (C.c_int, [_H, C.c_void_p]),
     "gcm_grey_radiation": (C.c_int, [_H] + [C.c_double] * 4 + [_dp, _dp, C.c_void_p, C.c_void_p]),

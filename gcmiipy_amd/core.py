@@ -185,6 +185,19 @@ class Core:
         sum |q - roll(q, -1, 0)| over axis 0 of the reference layout, by a device reduction"""
         return self.diag(_lib.DIAG_TV_P + int(field))
 
+    def polar_filter(self, q):
+        """low_pass.arakawa_1977 on a (H, W) or (n, H, W) field of this handle's grid (any n: the
+        levels go through the handle `layers` at a time)"""
+        a = as_f64(q, name="q")
+        if a.ndim not in (2, 3) or a.shape[-2:] != (self.H, self.W):
+            raise ValueError("q has shape %s, expected (..., %d, %d)" % (a.shape, self.H, self.W))
+        a3 = a.reshape(-1, self.H, self.W)
+        out = np.empty_like(a3)
+        for k0 in range(0, a3.shape[0], self.L):
+            k1 = min(k0 + self.L, a3.shape[0])
+            _check(lib.gcm_polar_filter(self._h, k1 - k0, _ptr(a3[k0:k1]), _ptr(out[k0:k1])), self._h)
+        return out.reshape(a.shape)
+
     # -- column physics (GCM_PE25D) ----------------------------------------------------
     def set_ground(self, gt):
         _check(lib.gcm_set_ground(self._h, _ptr(as_f64(gt, (self.H, self.W), "gt"))), self._h)

@@ -1001,6 +1001,13 @@ int gcm_set_ground(gcm_handle *h, const double *gt) {
     return pe25d_ground(h->pe, true, gt, nullptr, h->stream, &h->err);
 }
 
+int gcm_polar_filter(gcm_handle *h, int nlev, const double *in, double *out) {
+    if (!h || !in || !out) return GCM_ERR_ARG;
+    if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_polar_filter: GCM_PE25D only");
+    if (h->cfg.device >= 0) HIPCHK(h, hipSetDevice(h->cfg.device));
+    return pe25d_filter_field(h->pe, nlev, in, out, h->stream, &h->err);
+}
+
 int gcm_get_ground(gcm_handle *h, double *gt) {
     if (!h || !gt) return GCM_ERR_ARG;
     if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_get_ground: GCM_PE25D only");

@@ -2157,6 +2157,61 @@ int pe25d_halo_segments(Pe25d *m, bool pack, int side, void *dev_buf, SegCopy *c
     return GCM_OK;
 }
 
+// low_pass.arakawa_1977 on a field of the handle's grid, nlev <= L levels, host [nlev][H][W] in and
+// out: the spu filter kernel with iph(sp) = 1 (su * 1 is exact).  spu, pgfu and pit serve as scratch
+// -- every stage rewrites them before it reads them.
+template <typename T>
+__global__ void pe_fill_kernel(T *dst, long n, T x) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) dst[e] = x;
+}
+template <typename T>
+static int filter_field_t(Pe25d *m, int nlev, const double *in, double *out, hipStream_t s, std::string *err) {
+    PeBufs<T> &B = bufs<T>(m);
+    const int W = m->W, H = m->H;
+    const size_t bytes = sizeof(double) * (size_t)nlev * H * W;
+    hipError_t e = hipMemcpyAsync(m->stage3, in, bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(pe_to_device_kernel<T>, dim3(1024), dim3(256), 0, s, B.pgfu, m->stage3, W, H, nlev);
+        hipLaunchKernelGGL(pe_fill_kernel<T>, dim3(256), dim3(256), 0, s, B.pit, (long)H * W, T(1.0));
+        PeArgsT<T> a = make_args<T>(m, m->cur_i, m->cur_i, 0.0);
+        a.L = nlev;
+        a.sp = B.pit;
+        a.su = B.pgfu;
+        a.spu = B.spu;
+        a.filter = 1;
+        a.j0 = 0;
+        a.j1 = H;
+        const int fft_threads = m->cplan.ok ? m->cplan.threads : kFftThreads;
+        hipLaunchKernelGGL(spu_filter_kernel_for<T>(m->cplan), dim3(H, (nlev + 1) / 2), dim3(fft_threads),
+                           filter_lds_bytes<T>(m), s, a);
+        hipLaunchKernelGGL(pe_to_host_kernel<T>, dim3(1024), dim3(256), 0, s, m->stage3, B.spu, W, H, nlev);
+        e = hipMemcpyAsync(out, m->stage3, bytes, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        *err = std::string("pe25d polar filter: ") + hipGetErrorString(e);
+        return GCM_ERR_HIP;
+    }
+    return GCM_OK;
+}
+
+int pe25d_filter_field(Pe25d *m, int nlev, const double *in, double *out, hipStream_t s, std::string *err) {
+    if (nlev < 1 || nlev > m->L) {
+        *err = "polar filter: 1 <= levels <= the handle's layers";
+        return GCM_ERR_ARG;
+    }
+    if (!m->cfg.filter && m->W > 1) {
+        *err = "polar filter: the handle was created with filter = 0";
+        return GCM_ERR_UNSUPPORTED;
+    }
+    if (m->W == 1) {                                    // low_pass.py:58-59: identity
+        if (out != in) memcpy(out, in, sizeof(double) * (size_t)nlev * m->H);
+        return GCM_OK;
+    }
+    return m->f32 ? filter_field_t<float>(m, nlev, in, out, s, err) : filter_field_t<double>(m, nlev, in, out, s, err);
+}
+
 int pe25d_ground(Pe25d *m, bool set, const double *in, double *out, hipStream_t s, std::string *err) {
     const size_t bytes = sizeof(double) * (size_t)m->H * m->W;
     if (!m->gt) {

@@ -180,6 +180,10 @@ int gcm_energy(gcm_handle *h, const double *area, int area_len, double *out4);
  *                       -> dTdt [L][H][W], dt_ground [H][W] (either may be NULL)  grey_solar.py:358-563
  *   gcm_solar_step      no_limits_2_5d.solar_timestep: theta and gt advanced in place by dt
  *                       (the reference passes t_lw = 0.1, t_sw = 0.9, albedo = 0.3)  no_limits_2_5d.py:66-75 */
+/* low_pass.arakawa_1977(q, geom) (low_pass.py:41-78) on its own, GCM_PE25D handles: the zonal Fourier
+ * damping of nlev <= layers levels of a field on the handle's grid, host [nlev][H][W] float64 in and
+ * out (may alias).  Rows are filtered with the multiplier of their global latitude.              */
+int gcm_polar_filter(gcm_handle *h, int nlev, const double *in, double *out);
 int gcm_set_ground(gcm_handle *h, const double *gt);
 int gcm_get_ground(gcm_handle *h, double *gt);
 int gcm_grey_radiation(gcm_handle *h, double utc, double t_lw, double t_sw, double albedo,
