@@ -212,6 +212,48 @@ __global__ __launch_bounds__(256) void pe1d_half_kernel(Pe1dArgs a) {
     a.qo[i] = q_n;
 }
 
+// The operators of matsuno_c_grid.py / viscosity.py / matsumo_temp.py / temperature.py one by one
+// (the fused step kernels evaluate the same device functions): one thread per cell, periodic in
+// both axes as the reference's rolls.  c0 = dx, c1 = mu where the operator has them.
+__global__ __launch_bounds__(256) void sw2d_op_kernel(int kind, int W, int H, const double *x0, const double *x1,
+                                                     const double *x2, double *out, double c0, double c1,
+                                                     const double *etab) {
+    __shared__ double tab[kExnerTabDoubles];
+    tab[threadIdx.y * 64 + threadIdx.x] = etab[threadIdx.y * 64 + threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y * 4 + threadIdx.y;
+    if (i >= W || j >= H) return;
+    const long o = (long)j * W + i;
+    const long ow = at2(j, i - 1, H, W), oe = at2(j, i + 1, H, W), on = at2(j - 1, i, H, W), os = at2(j + 1, i, H, W),
+               osw = at2(j + 1, i - 1, H, W);
+    const double dx = c0;
+    double r = 0.0;
+    switch (kind) {
+        case GCM_OP_ADV_U:                                            // matsuno_c_grid.py:15-51
+            r = adv_vel_u(x0[o], x0[ow], x0[oe], x0[on], x0[os], x1[o], x1[ow], x1[os], x1[osw], 0.5 / dx);
+            break;
+        case GCM_OP_ADV_V:                                            // :54-80
+            r = adv_vel_v(x1[o], x1[ow], x1[oe], x1[on], x1[os], x0[o], x0[on], x0[ow], x0[osw], 0.5 / dx);
+            break;
+        case GCM_OP_GEO_GRAD_U: r = geo_grad(x0[oe], x0[o], kG / dx); break;      // :97-100
+        case GCM_OP_GEO_GRAD_V: r = geo_grad(x0[os], x0[o], kG / dx); break;      // :103-106
+        case GCM_OP_ADV_GEO:                                          // :109-118
+            r = adv_geo(x0[o], x0[ow], x1[o], x1[on], x2[o], x2[ow], x2[oe], x2[on], x2[os], 0.5 / dx);
+            break;
+        case GCM_OP_LAPLACIAN: r = visc_u(x0[o], x0[ow], x0[oe], x0[on], x0[os], 1.0 / (dx * dx)); break;   // viscosity.py:12-19
+        case GCM_OP_VISCOSITY: r = visc_u(x0[o], x0[ow], x0[oe], x0[on], x0[os], c1 / (dx * dx)); break;    // :22-25
+        case GCM_OP_DENSITY_FROM: r = x0[o] / (kRd * (x1[o] * exner(x0[o], tab))); break;                  // matsumo_temp.py:13-19
+        case GCM_OP_GEOPOTENTIAL_FROM: r = x1[o] / (kG * x0[o]); break;                                    // :45-47
+        case GCM_OP_TO_TRUE_TEMP: r = x0[o] * exner(x1[o], tab); break;           // temperature.py:7-12
+        case GCM_OP_TO_POTENTIAL_TEMP: r = x0[o] / exner(x1[o], tab); break;      // :15-19; matsumo_temp.py:22-25
+        case GCM_OP_TO_DENSITY: r = x1[o] / (kRd * x0[o]); break;                 // :22-24
+        case GCM_OP_SCALING: r = x0[o] * x1[o] * dx * dx; break;                  // matsumo_temp.py:28-30
+        case GCM_OP_UNSCALING: r = x1[o] / (x0[o] * dx * dx); break;              // :33-35
+        default: break;
+    }
+    out[o] = r;
+}
+
 thread_local std::string g_ops_error;
 int ops_fail(int code, const char *m) { g_ops_error = m; return code; }
 }  // namespace
@@ -295,6 +337,30 @@ int gcm_pe1d(int n, int nsteps, int half_only, double dt, double dx, const doubl
     for (int f = 0; f < 4; ++f)
         if (hipMemcpy(out[f], o[f], (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
             return ops_fail(GCM_ERR_HIP, "gcm_pe1d: kernel or copy-back failed");
+    return GCM_OK;
+}
+
+int gcm_sw2d_op(int kind, int width, int height, double dx, double mu, const double *x0, const double *x1,
+                const double *x2, double *out) {
+    static const int nin[] = {2, 2, 1, 1, 3, 1, 1, 2, 2, 2, 2, 2, 2, 2};
+    if (kind < 0 || kind > GCM_OP_UNSCALING || width < 1 || height < 1 || !out || !x0 || (nin[kind] > 1 && !x1) ||
+        (nin[kind] > 2 && !x2))
+        return ops_fail(GCM_ERR_ARG, "gcm_sw2d_op: bad argument");
+    const bool uses_dx = kind <= GCM_OP_VISCOSITY || kind >= GCM_OP_SCALING;
+    if (uses_dx && !(dx != 0.0)) return ops_fail(GCM_ERR_ARG, "gcm_sw2d_op: dx must be non-zero");
+    if (gcm_device_count() < 1) return ops_fail(GCM_ERR_NODEVICE, "gcm_sw2d_op: no HIP device; no CPU fallback");
+    const size_t n = (size_t)width * height;
+    DevBuf mem;
+    double tab[kExnerTabDoubles];
+    build_exner_table(tab);
+    double *d0 = mem.get(n, x0), *d1 = nin[kind] > 1 ? mem.get(n, x1) : nullptr, *d2 = nin[kind] > 2 ? mem.get(n, x2) : nullptr,
+           *o = mem.get(n), *dtab = mem.get(kExnerTabDoubles, tab);
+    if (!d0 || (nin[kind] > 1 && !d1) || (nin[kind] > 2 && !d2) || !o || !dtab)
+        return ops_fail(GCM_ERR_HIP, "gcm_sw2d_op: device allocation failed");
+    hipLaunchKernelGGL(sw2d_op_kernel, dim3((width + 63) / 64, (height + 3) / 4), dim3(64, 4), 0, nullptr, kind, width, height,
+                       d0, d1, d2, o, dx, mu, dtab);
+    if (hipMemcpy(out, o, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return ops_fail(GCM_ERR_HIP, "gcm_sw2d_op: kernel or copy-back failed");
     return GCM_OK;
 }
 

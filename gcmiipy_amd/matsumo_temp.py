@@ -43,3 +43,8 @@ def run_with_callbacks(i, u, v, p, t, dx, dt, callbacks=None):
     for callback in callbacks or []:
         callback(u, v, p, t, i)
     return u, v, p, t
+
+
+# the operators the step is made of, one by one (matsumo_temp.py:13-47): SI magnitudes out
+from .operators import (density_from, potential_temperature, scaling, unscaling, advect_t,  # noqa: E402,F401
+                        geopotential_from)

@@ -67,3 +67,8 @@ def run(u, v, p, dx, dt, steps, callback=None, every=1):
     finally:
         c.close()
     return attach(un, uu), attach(vn, vu), attach(pn, pu)
+
+
+# the operators the step is made of, one by one (matsuno_c_grid.py:15-118): SI magnitudes out
+from .operators import (advection_of_velocity_u, advection_of_velocity_v, geopotential_gradient_u,  # noqa: E402,F401
+                        geopotential_gradient_v, advection_of_geopotential)

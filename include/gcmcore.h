@@ -279,6 +279,29 @@ int gcm_advect2d(int scheme, int axes, int finite, int width, int height, int ns
  * of n cells is height n, width 1.                                                          */
 int gcm_pgf2d(int kind, int width, int height, double dt, double dx0, double dx1, const double *p,
               const double *t, double *out2);
+/* The 2-D operators the step kernels are fused from, one by one (host float64 arrays [H][W] in and
+ * out, periodic in both axes as the reference's np.roll shifts): what matsuno_c_grid.py,
+ * viscosity.py, matsumo_temp.py and temperature.py export.  Inputs x0, x1, x2 in the reference's
+ * argument order; dx, mu where the operator takes them (else ignored).  The elementwise ones take
+ * any array as height 1, width n.                                                            */
+typedef enum {
+    GCM_OP_ADV_U = 0,             /* advection_of_velocity_u(u, v, dx)        matsuno_c_grid.py:15-51  */
+    GCM_OP_ADV_V = 1,             /* advection_of_velocity_v(u, v, dx)        :54-80                   */
+    GCM_OP_GEO_GRAD_U = 2,        /* geopotential_gradient_u(p, dx)           :97-100                  */
+    GCM_OP_GEO_GRAD_V = 3,        /* geopotential_gradient_v(p, dx)           :103-106                 */
+    GCM_OP_ADV_GEO = 4,           /* advection_of_geopotential(u, v, p, dx)   :109-118                 */
+    GCM_OP_LAPLACIAN = 5,         /* finite_laplacian_2d(q, dx)               viscosity.py:12-19       */
+    GCM_OP_VISCOSITY = 6,         /* incompressible_viscosity_2d(u, mu, dx)   :22-25                   */
+    GCM_OP_DENSITY_FROM = 7,      /* density_from(p, t)                       matsumo_temp.py:13-19    */
+    GCM_OP_GEOPOTENTIAL_FROM = 8, /* geopotential_from(rho, p)                :45-47                   */
+    GCM_OP_TO_TRUE_TEMP = 9,      /* to_true_temp(t, p)                       temperature.py:7-12      */
+    GCM_OP_TO_POTENTIAL_TEMP = 10,/* to_potential_temp(tt, p)                 :15-19                   */
+    GCM_OP_TO_DENSITY = 11,       /* to_density(tt, p)                        :22-24                   */
+    GCM_OP_SCALING = 12,          /* scaling(pa, t, dx)                       matsumo_temp.py:28-30    */
+    GCM_OP_UNSCALING = 13         /* unscaling(pb, tt, dx)                    :33-35                   */
+} gcm_sw2d_op_kind;
+int gcm_sw2d_op(int kind, int width, int height, double dx, double mu, const double *x0, const double *x1,
+                const double *x2, double *out);
 /* flux_limiter.py on 1-D arrays of n cells (host arrays in/out; ip/im = np.roll by -1/+1,
  * coordinates_1d.py:25-30).  Results are BIT-identical to NumPy's, masks included: IEEE division,
  * no contraction.
