@@ -272,6 +272,29 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
         if life is not None and since[0]:
             core.restore()
             since[0] = 0
+    # Deep-halo bands whose exchange the library posts itself: the exchange can be hidden behind the
+    # interior rows of the steps around it at the price of four more launches per window
+    # (gcm_set_band_overlap).  Whether that pays depends on what the exchange costs between THESE
+    # devices, so both sequences are timed here (max over ranks) and the faster one is kept.
+    overlap_probe = None
+    if active and world > 1 and not solo and k > 1 and model != "PE25D" and getattr(runner, "native", False):
+        overlap_probe = {}
+        for flag in (0, 1):
+            core.set_band_overlap(flag)
+            run(2 * k)
+            fence()
+            t0 = time.perf_counter()
+            run(6 * k)
+            fence()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                              device="cuda" if cx.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            overlap_probe["overlap" if flag else "plain"] = float(tt.item()) / (6 * k) * 1e3
+        overlap_probe["chosen"] = "overlap" if overlap_probe["overlap"] < overlap_probe["plain"] else "plain"
+        core.set_band_overlap(overlap_probe["chosen"] == "overlap")
+        if life is not None and since[0]:
+            core.restore()
+            since[0] = 0
     run(warmup)
     # The timed region: a block of exactly `steps` steps between two fences (barrier + synchronize),
     # repeated until MIN_TIMED_S seconds have been timed (every rank sees the same all-reduced block
@@ -305,6 +328,7 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
                "bytes_per_cell_update": bpc,
                "hbm_roofline_frac_whole_job": value * bpc / (world * HBM_PEAK_GBS * 1e9),
                "exchange": cx.exchange if world > 1 else None,
+               "band_overlap_probe_ms_per_step": overlap_probe,
                "decomposition": "%d latitude band(s)%s" % (
                    world, ", ghost rows exchanged every %d steps" % k if world > 1 and k > 1 else "")}
         if world > 1:

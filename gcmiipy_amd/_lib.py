@@ -89,6 +89,7 @@ SYMBOLS = {
     "gcm_step_phase": (C.c_int, [_H, C.c_int, C.c_double, C.c_void_p]),
     "gcm_set_exchange": (C.c_int, [_H, C.POINTER(Exchange)]),
     "gcm_band_run": (C.c_int, [_H, C.c_int, C.c_double]),
+    "gcm_set_band_overlap": (C.c_int, [_H, C.c_int]),
     "gcm_sync": (C.c_int, [_H]),
     "gcm_advect2d": (C.c_int, [C.c_int] * 6 + [C.c_double] * 3 + [C.c_void_p] * 3),
     "gcm_pgf2d": (C.c_int, [C.c_int] * 3 + [C.c_double] * 3 + [C.c_void_p] * 3),

@@ -272,6 +272,10 @@ class Core:
             x.send, x.recv, x.group_start, x.group_end = rccl.entry_points()
         _check(lib.gcm_set_exchange(self._h, C.byref(x)), self._h)
 
+    def set_band_overlap(self, on):
+        """deep-halo 2-D bands: hide the exchange behind interior rows (gcm_set_band_overlap)"""
+        _check(lib.gcm_set_band_overlap(self._h, 1 if on else 0), self._h)
+
     def band_run(self, nsteps, dt):
         """`nsteps` full band steps, exchanges included, one library call (gcm_band_run)"""
         _check(lib.gcm_band_run(self._h, int(nsteps), float(dt)), self._h)

@@ -59,6 +59,8 @@ struct gcm_handle {
     // gcm_band_run: the exchange the library posts itself
     gcm_exchange xch{};
     bool xch_set = false, primed = false;
+    bool xch_inflight = false;                 // gcm_band_run: an exchange posted, its unpack still to come
+    bool band_overlap = false;                 // deep-halo bands: hide the exchange behind interior rows (gcm_set_band_overlap)
     hipEvent_t ev_pack = nullptr, ev_comm = nullptr;
     // GCM_PE25D band step as a hipGraph, one per parity of the current state set (the step ping-pongs
     // between two sets): ~40 launches / event calls per step become one graph launch
@@ -677,6 +679,7 @@ int gcm_set_exchange(gcm_handle *h, const gcm_exchange *x) {
     h->xch = *x;
     h->xch_set = true;
     h->primed = false;
+    if (const char *e = getenv("GCM_BAND_OVERLAP")) h->band_overlap = e[0] == '1';
     for (int g = 0; g < 2; ++g) {                           // captured with the previous exchange
         if (h->step_graph[g]) (void)hipGraphExecDestroy(h->step_graph[g]);
         h->step_graph[g] = nullptr;
@@ -697,8 +700,8 @@ int gcm_set_exchange(gcm_handle *h, const gcm_exchange *x) {
 }  // extern "C"
 
 // the send buffers are packed (or being packed: the caller has made the comm stream wait for that);
-// post the ring exchange on the comm stream, then unpack into the ghost rows on the compute stream
-static int band_exchange(gcm_handle *h) {
+// post the ring exchange on the comm stream ...
+static int band_post(gcm_handle *h) {
     const gcm_exchange &x = h->xch;
     const size_t nbytes = gcm_halo_bytes(h);
     hipStream_t cs = h->comm;
@@ -725,8 +728,16 @@ static int band_exchange(gcm_handle *h) {
         HIPCHK(h, hipMemcpyAsync(x.recv_north, x.send_south, nbytes, hipMemcpyDeviceToDevice, cs));
     }
     HIPCHK(h, hipEventRecord(h->ev_comm, cs));
+    return GCM_OK;
+}
+// ... and the other half: the compute stream waits for the exchange and fills the ghost rows
+static int band_finish(gcm_handle *h) {
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_comm, 0));
-    return gcm_halo_unpack2(h, x.recv_north, x.recv_south, h->stream);
+    return gcm_halo_unpack2(h, h->xch.recv_north, h->xch.recv_south, h->stream);
+}
+static int band_exchange(gcm_handle *h) {
+    const int rc = band_post(h);
+    return rc ? rc : band_finish(h);
 }
 
 // pack both edges on the compute stream, then exchange (the comm stream waits for the pack only)
@@ -805,6 +816,13 @@ static int band_step_pe_graph(gcm_handle *h, double dt) {
 
 extern "C" {
 
+int gcm_set_band_overlap(gcm_handle *h, int on) {
+    if (!h) return GCM_ERR_ARG;
+    if (h->wrap) return fail(h, GCM_ERR_STATE, "gcm_set_band_overlap: handle is not a latitude band");
+    h->band_overlap = on != 0;
+    return GCM_OK;
+}
+
 int gcm_band_run(gcm_handle *h, int nsteps, double dt) {
     if (!h || nsteps < 0) return GCM_ERR_ARG;
     if (h->wrap) return fail(h, GCM_ERR_STATE, "gcm_band_run: handle is not a latitude band");
@@ -821,6 +839,7 @@ int gcm_band_run(gcm_handle *h, int nsteps, double dt) {
         return GCM_OK;
     }
     const int k = h->G / kGhost;                            // steps per exchange
+    const bool overlap = k > 1 && h->band_overlap && h->H > 2 * h->G + 2 * kGhost;
     int done = 0;
     while (done < nsteps) {
         if (k == 1) {
@@ -834,14 +853,73 @@ int gcm_band_run(gcm_handle *h, int nsteps, double dt) {
             ++done;
             continue;
         }
-        if (!h->primed || h->since_exchange >= k) {
-            if ((rc = band_pack_exchange(h))) return rc;
+        if (!overlap) {
+            if (!h->primed || h->since_exchange >= k) {
+                if ((rc = band_pack_exchange(h))) return rc;
+                h->primed = true;
+            }
+            const int n = std::min(k - h->since_exchange, nsteps - done);
+            if ((rc = gcm_step(h, n, dt))) return rc;
+            done += n;
+            continue;
+        }
+        // Deep halo (an exchange every k steps) with the exchange hidden behind two steps' interior
+        // rows.  The LAST step of a window produces the G edge rows of either side first; they are
+        // packed and sent while the rest of that step runs.  The FIRST step of the next window starts
+        // with the rows that need no ghost data; only then does the compute stream wait for the
+        // exchange, fill the ghost rows and produce the rows next to them.  Same kernels on the same
+        // rows as the plain sequence: bit-identical.
+        hipStream_t st = h->stream;
+        const int H = h->H, G = h->G;
+        if (!h->primed || (h->since_exchange >= k && !h->xch_inflight)) {
+            if ((rc = gcm_halo_pack2(h, h->xch.send_north, h->xch.send_south, st))) return rc;
+            HIPCHK(h, hipEventRecord(h->ev_pack, st));
+            HIPCHK(h, hipStreamWaitEvent(h->comm, h->ev_pack, 0));
+            if ((rc = band_post(h))) return rc;
+            h->xch_inflight = true;
             h->primed = true;
         }
-        const int n = std::min(k - h->since_exchange, nsteps - done);
-        if ((rc = gcm_step(h, n, dt))) return rc;
-        done += n;
+        if (h->xch_inflight) {                              // first step of a window, split
+            const int e = G - kGhost;
+            step_rows(h, dt, kGhost, H - kGhost, st);
+            if ((rc = band_finish(h))) return rc;           // (resets since_exchange)
+            h->xch_inflight = false;
+            step_rows(h, dt, -e, kGhost, st);
+            step_rows(h, dt, H - kGhost, H + e, st);
+            swap_state(h);
+            h->since_exchange = 1;
+            ++done;
+        }
+        while (done < nsteps && h->since_exchange < k - 1) {
+            const int e = G - kGhost * (h->since_exchange + 1);
+            step_rows(h, dt, -e, H + e, st);
+            swap_state(h);
+            ++h->since_exchange;
+            ++done;
+        }
+        if (done < nsteps && h->since_exchange == k - 1) {   // last step of the window: no ghost rows left to use
+            step_rows(h, dt, 0, G, st);
+            step_rows(h, dt, H - G, H, st);
+            swap_state(h);                                  // the pack reads the state being produced
+            rc = gcm_halo_pack2(h, h->xch.send_north, h->xch.send_south, st);
+            swap_state(h);
+            if (rc) return rc;
+            HIPCHK(h, hipEventRecord(h->ev_pack, st));
+            HIPCHK(h, hipStreamWaitEvent(h->comm, h->ev_pack, 0));
+            if ((rc = band_post(h))) return rc;
+            h->xch_inflight = true;
+            step_rows(h, dt, G, H - G, st);
+            swap_state(h);
+            h->since_exchange = k;
+            ++done;
+        }
     }
+    if (h->xch_inflight) {                                  // nothing is left pending across calls
+        if ((rc = band_finish(h))) return rc;
+        h->xch_inflight = false;
+    }
+    h->star_valid = false;
+    HIPCHK(h, hipGetLastError());
     return GCM_OK;
 }
 

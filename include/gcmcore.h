@@ -254,6 +254,13 @@ typedef struct {
 } gcm_exchange;
 int gcm_set_exchange(gcm_handle *h, const gcm_exchange *x);   /* NULL: unregister */
 int gcm_band_run(gcm_handle *h, int nsteps, double dt);
+/* 2-D models with halo_steps > 1 (an exchange every k steps): on = 1 hides the exchange behind the
+ * interior rows of the step before and the step after it (the last step of a window produces, packs
+ * and sends its edge rows first; the first step of the next starts with the rows that need no ghost
+ * data).  Same kernels on the same rows: bit-identical results.  Costs four more launches per window,
+ * so it pays where the exchange takes longer than that (measured per run by bench.py --gpus N, which
+ * times both and keeps the faster).  Default off, or GCM_BAND_OVERLAP=1 at gcm_set_exchange.       */
+int gcm_set_band_overlap(gcm_handle *h, int on);
 
 int gcm_sync(gcm_handle *h);
 

@@ -483,11 +483,16 @@ def test_band_runner_over_rccl_self_ring(tmp_path, model):
         assert np.array_equal(got[k], w), k
 
 
-@pytest.mark.parametrize("model", ["pe", "c3", "c3deep"])
+@pytest.mark.parametrize("model", ["pe", "c3", "c3deep", "c3deep-overlap", "c3deep8-overlap"])
 def test_band_run_native_loopback_equals_single_domain(model):
     """gcm_band_run with the loopback exchange (gcm_set_exchange without RCCL entry points): the band
     is its own neighbour, i.e. the periodic single domain -- bit-identical to it, and to the
-    host-driven sequence.  Also the error paths of gcm_set_exchange / gcm_band_run."""
+    host-driven sequence.  "-overlap": the deep-halo exchange hidden behind the interior rows of the
+    steps around it (gcm_set_band_overlap), runs cut at every position of a window.  Also the error
+    paths of gcm_set_exchange / gcm_band_run."""
+    overlap = model.endswith("-overlap")
+    halo = 8 if model.startswith("c3deep8") else 4 if model.startswith("c3deep") else 1
+    model = model.split("-")[0].replace("8", "")
     import torch
     import gcmiipy_amd as g
     from gcmiipy_amd import geometry
@@ -499,7 +504,7 @@ def test_band_run_native_loopback_equals_single_domain(model):
         mk = lambda **kw: g.Core(g._lib.PE25D, W, H, L, geom=geom, **kw)
         ic = dict(zip(("p", "u", "v", "t", "q"), _ic_pe(geom)))
     else:
-        H, W, steps, dt = 64, 130, 11, 300.0
+        H, W, steps, dt = 64, 130, 11 if not overlap else 23, 300.0
         mk = lambda **kw: g.Core(g._lib.SW2D_TEMP, W, H, dx=300e3, tracer=g._lib.TRACER_VANLEER, **kw)
         ic = _ic2d((H, W))
     ref = mk()
@@ -510,15 +515,20 @@ def test_band_run_native_loopback_equals_single_domain(model):
         ref.band_run(1, dt)
     ref.close()
     c = mk(nranks=2, rank=0, global_height=H, row0=0, stream=torch.cuda.current_stream().cuda_stream,
-           halo_steps=4 if model == "c3deep" else 1)
+           halo_steps=halo)
     c.set_state(**ic)
     with pytest.raises(GcmError, match="no exchange registered"):
         c.band_run(1, dt)
     eng = HipBandEngine(c, torch)
     runner = BandRunner(eng, 0, 2, LoopbackExchange(), north=0, south=0)
     assert runner.native
-    runner.run(3, dt)
-    runner.run(steps - 3, dt)
+    if overlap:
+        c.set_band_overlap(True)
+        for n in (1, 2, 3, 5, 4, 8):                    # ends inside, at the end and at the start of a window
+            runner.run(n, dt)
+    else:
+        runner.run(3, dt)
+        runner.run(steps - 3, dt)
     torch.cuda.synchronize()
     got = c.get_state()
     c.close()
