@@ -688,8 +688,10 @@ int gcm_set_exchange(gcm_handle *h, const gcm_exchange *x) {
         // off by default: replaying the step as a graph measured 3 % (N = 8 band of the 1440x720x24 grid:
         // 0.416 vs 0.430 ms; the gaps between the small kernels of a band are GPU-side), and a captured
         // RCCL exchange between devices cannot be rehearsed on the one-GPU development box
+        // Only with the loopback exchange: capturing RCCL's send/recv group (self-ring, one GPU)
+        // segfaults inside the capture on this ROCm, whichever stream carries it.
         const char *e = getenv("GCM_BAND_GRAPH");
-        h->graph_ok = e && e[0] == '1';
+        h->graph_ok = e && e[0] == '1' && x->send == nullptr;
     }
     // GCM_PE25D: the edge rows of a stage are updated and packed into the send buffers on the
     // handle's second stream (gcm_set_halo_buffers)
@@ -701,10 +703,10 @@ int gcm_set_exchange(gcm_handle *h, const gcm_exchange *x) {
 
 // the send buffers are packed (or being packed: the caller has made the comm stream wait for that);
 // post the ring exchange on the comm stream ...
-static int band_post(gcm_handle *h, bool on_compute_stream = false) {
+static int band_post(gcm_handle *h, bool on_compute_stream = false, hipStream_t on = nullptr) {
     const gcm_exchange &x = h->xch;
     const size_t nbytes = gcm_halo_bytes(h);
-    hipStream_t cs = on_compute_stream ? h->stream : h->comm;
+    hipStream_t cs = on ? on : on_compute_stream ? h->stream : h->comm;
     if (x.send) {
         int rc = x.group_start();
         if (rc == 0) {
@@ -727,7 +729,7 @@ static int band_post(gcm_handle *h, bool on_compute_stream = false) {
         HIPCHK(h, hipMemcpyAsync(x.recv_south, x.send_north, nbytes, hipMemcpyDeviceToDevice, cs));
         HIPCHK(h, hipMemcpyAsync(x.recv_north, x.send_south, nbytes, hipMemcpyDeviceToDevice, cs));
     }
-    if (!on_compute_stream) HIPCHK(h, hipEventRecord(h->ev_comm, cs));
+    if (!on_compute_stream && !on) HIPCHK(h, hipEventRecord(h->ev_comm, cs));
     return GCM_OK;
 }
 // ... and the other half: the compute stream waits for the exchange and fills the ghost rows
@@ -753,11 +755,26 @@ static int band_pack_exchange(gcm_handle *h) {
 // rows on the compute stream, then the exchange behind the pack (it overlaps the interior rows)
 static int band_step_pe(gcm_handle *h, double dt) {
     int rc = GCM_OK;
+    // The exchange follows the edge rows' pack on the SAME stream (the handle's second one), and so
+    // does the unpack: no cross-queue dependency between pack, send/recv and unpack (each costs
+    // 10-20 us on this chip; trace of the N = 8 band); the compute stream joins once, after the
+    // unpack.  GCM_BAND_COMM_STREAM=1: the exchange on the comm stream, as before.
+    static const bool on_comm = getenv("GCM_BAND_COMM_STREAM") && getenv("GCM_BAND_COMM_STREAM")[0] == '1';
+    hipStream_t ax = on_comm ? nullptr : pe25d_aux_stream(h->pe);
     for (int stage = 0; stage < 2; ++stage) {
         if ((rc = pe25d_step_phase(h->pe, 2 * stage, dt, h->stream, &h->err))) return rc;
+        if (ax) {
+            if ((rc = band_post(h, false, ax))) return rc;
+            if ((rc = gcm_halo_unpack2(h, h->xch.recv_north, h->xch.recv_south, ax))) return rc;
+            HIPCHK(h, hipEventRecord(h->ev_comm, ax));
+        }
         if ((rc = pe25d_step_phase(h->pe, 2 * stage + 1, dt, h->stream, &h->err))) return rc;
-        if ((rc = pe25d_wait_edges(h->pe, h->comm, &h->err))) return rc;
-        if ((rc = band_exchange(h))) return rc;
+        if (ax) {
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_comm, 0));
+        } else {
+            if ((rc = pe25d_wait_edges(h->pe, h->comm, &h->err))) return rc;
+            if ((rc = band_exchange(h))) return rc;
+        }
     }
     return GCM_OK;
 }

@@ -398,8 +398,18 @@ template <typename T>
 __device__ __forceinline__ T cs_acc(T acc, T x, T dsg) { return fma(x, dsg, acc); }
 template <typename T>
 __device__ __forceinline__ T column_sum(const T *col, const T *dsig, int L, int W) {
+    // eight levels requested at a time, then added in order (a load per iteration waits a memory
+    // latency per level: 20 us for the two ghost rows of a band, on the stage's critical path)
     T acc = T(0.0);
-    for (int k = L - 1; k >= 0; --k) acc = cs_acc(acc, col[(long)k * W], dsig[k]);
+    int k = L - 1;
+    for (; k >= 7; k -= 8) {
+        T x[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) x[n] = col[(long)(k - n) * W];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc = cs_acc(acc, x[n], dsig[k - n]);
+    }
+    for (; k >= 0; --k) acc = cs_acc(acc, col[(long)k * W], dsig[k]);
     return acc;
 }
 // U, V of the stage state's rows [j0, j1) and [jb0, jb1): the rows no K4 has produced them for (a
