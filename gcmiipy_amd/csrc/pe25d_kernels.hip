@@ -385,6 +385,51 @@ __global__ __launch_bounds__(256) void pe_pit_kernel(PeArgsT<T> a) {
     }
 }
 
+// The partial sums of conv at the segment boundaries alone (pit itself comes from pe_pit2d_kernel),
+// rows [j0, j1) and [jb0, jb1): a band's edge rows, which K4 marches in level segments so that they
+// are done -- and on their way to the neighbours -- long before the interior rows (a K4 workgroup
+// is a chain of L dependent levels, however few rows it has).  Same accumulation as pe_pit_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void pe_part_kernel(PeArgsT<T> a) {
+    const Idx ix{a.W, a.H, a.L, a.wrap};
+    const int W = a.W, L = a.L;
+    const int iblocks = (W + 255) / 256;
+    const int jrel = blockIdx.x / iblocks;
+    const int i = (blockIdx.x - jrel * iblocks) * 256 + threadIdx.x;
+    const int na = a.j1 - a.j0;
+    if (i >= W || jrel >= na + (a.jb1 - a.jb0)) return;
+    const int j = jrel < na ? a.j0 + jrel : a.jb0 + (jrel - na);
+    const int iw = i == 0 ? W - 1 : i - 1;
+    const int jg = wrapi(a.row0 + j, a.Hg);
+    const T inv_dxj = a.inv_dxj[jg], inv_dy = a.inv_dy;
+    const T spc = a.sp[ix.r2(j) + i], spn = a.sp[ix.r2(j - 1) + i], sps = a.sp[ix.r2(j + 1) + i];
+    const T jph_c = (spc + sps) * T(0.5), jph_n = (spn + spc) * T(0.5);
+    const long c3 = ix.r3(j), n3 = ix.r3(j - 1);
+    T rc = T(0.0);
+    int s = a.nseg - 2;
+    int stop = seg_lo(s + 1, a.nseg, L);
+    // the levels of one segment are requested together, then accumulated in order
+    for (int k = L - 1; s >= 0;) {
+        constexpr int kB = 8;
+        T xu[kB], xw[kB], xv[kB], xn[kB];
+        const int n = min(kB, k - stop + 1);
+#pragma unroll
+        for (int m = 0; m < kB; ++m) {
+            const long o = (long)max(k - m, stop) * W;
+            xu[m] = a.spu[c3 + o + i]; xw[m] = a.spu[c3 + o + iw]; xv[m] = a.sv[c3 + o + i]; xn[m] = a.sv[n3 + o + i];
+        }
+#pragma unroll
+        for (int m = 0; m < kB; ++m)
+            if (m < n) rc = conv_acc(rc, xu[m], xw[m], inv_dxj, xv[m], jph_c, xn[m], jph_n, inv_dy, a.dsig[k - m]);
+        k -= n;
+        if (k < stop) {
+            a.part[(long)s * a.part_stride + ix.r2(j) + i] = rc;
+            --s;
+            if (s >= 0) stop = seg_lo(s + 1, a.nseg, L);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- K2b', the 2-D form of pit
 // The filter is linear and iph(sp), jph(sp) do not depend on the level, so
 //   pit = sum_k dsig[k] conv[k] = d_i( filter(iph(sp) U) ) / dx + d_j( jph(sp) V ) / dy,
@@ -1350,6 +1395,7 @@ struct Pe25d {
     int upd_rows = 7;                           // rows per workgroup of the row-group K4 (0: one-wave form)
     int cus = 256;
     bool pit2d = true;                          // pit from the column sums K4 leaves (nseg == 1, row-group K4)
+    int nseg_edge = 1;                          // bands: level segments of the EDGE rows' K4 launch (see half_t)
     bool cs_valid[3] = {false, false, false};   // the state set's column sums belong to its winds
     int pack_set = -1;                          // >= 0: state set gcm_halo_pack reads (step_phase)
     double *stage3 = nullptr;                   // float64 transpose staging, host layout
@@ -1703,6 +1749,11 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
         // segments) and then leaves the column sums pit needs: segments only on request, or for the
         // one-wave kernel
         if (m->upd_rows > 0 && !forced) m->nseg = 1;
+        if (!m->wrap && m->upd_rows > 0 && m->nseg == 1 && m->pit2d && m->H > 2 * kGhost) {
+            m->nseg_edge = std::min(kMaxSeg, std::max(1, L / 6));
+            if (const char *e = getenv("GCM_PE_EDGE_SEGMENTS")) m->nseg_edge = std::max(1, std::min(kMaxSeg, atoi(e)));
+            if (L / m->nseg_edge < 2) m->nseg_edge = 1;
+        }
     }
     if (const char *what = m->f32 ? alloc_all<float>(m, cfg) : alloc_all<double>(m, cfg)) return bad(what);
     if (!dev_upload<double>(m, &m->stage3, nullptr, (size_t)m->H * W * L)) return bad("staging");
@@ -1885,6 +1936,9 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
                 c.j1 = m->H + ext;
                 c.jb0 = c.jb1 = 0;
                 m->cs_valid[stage_set] = true;
+            } else if (m->nseg_edge > 1) {                   // + the own edge rows (marched in segments: no sums from K4)
+                c.j0 = -1; c.j1 = kGhost;
+                c.jb0 = m->H - kGhost; c.jb1 = m->H + 1;
             } else {
                 c.j0 = -1; c.j1 = 0;
                 c.jb0 = m->H; c.jb1 = m->H + 1;
@@ -1948,8 +2002,24 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         const bool as = async_edges(m);
         hipStream_t se = as && m->aux ? m->aux : s;
         if (as && m->aux) (void)hipStreamWaitEvent(m->aux, m->ev_a, 0);
-        if (split) update_rows(j0, j0 + kGhost, j1 - kGhost, j1, se);
-        else update_rows(j0, j1, 0, 0, se);
+        if (split && p2 && m->nseg_edge > 1) {
+            // the edge rows in level segments: a quarter of the chain of dependent levels, so the pack
+            // and the exchange start while the interior rows are still at work
+            PeArgsT<T> keep = a;
+            a.nseg = m->nseg_edge;
+            a.ocs_u = a.ocs_v = nullptr;
+            // the partial sums of conv they start from (launched behind K1 instead, beside K3, this
+            // kernel takes 14 us instead of 50 -- but on the stage's critical chain, a net loss)
+            a.j0 = j0; a.j1 = j0 + kGhost + 1;            // (K4 of row j also takes the sums of row j + 1)
+            a.jb0 = j1 - kGhost; a.jb1 = j1 + 1;
+            hipLaunchKernelGGL(pe_part_kernel<T>, dim3((unsigned)((W + 255) / 256) * (2 * kGhost + 2)), dim3(256), 0, se, a);
+            update_rows(j0, j0 + kGhost, j1 - kGhost, j1, se);
+            a = keep;
+        } else if (split) {
+            update_rows(j0, j0 + kGhost, j1 - kGhost, j1, se);
+        } else {
+            update_rows(j0, j1, 0, 0, se);
+        }
         if (as) {
             SegCopy c{};
             std::string err;
