@@ -21,6 +21,17 @@ ADV_UPWIND, ADV_FV_UPWIND, ADV_FV_PLAIN, ADV_VANLEER, ADV_MOMENTUM = range(5)
 DIAG_ANY_NAN, DIAG_MAX_U, DIAG_MEAN_P, DIAG_SUM_P, DIAG_MIN_U, DIAG_MAX_V, DIAG_MIN_V = range(7)
 DIAG_TV_P, DIAG_TV_U, DIAG_TV_V, DIAG_TV_T, DIAG_TV_Q = range(7, 12)
 FL_VAN_LEER, FL_CALC_R, FL_DONOR_FLUX, FL_DONOR_ADVECTION = range(4)
+(PEOP_CALC_PU, PEOP_CALC_PV, PEOP_UN_PU, PEOP_UN_PV, PEOP_AFLUX, PEOP_ADVEC_SIG, PEOP_ADVEC_M_PU, PEOP_GEOPOTENTIAL,
+ PEOP_PGF, PEOP_ADVEC_T) = range(10)
+
+
+class PeGeom(C.Structure):
+    """gcm_pe_geom"""
+    _fields_ = [("dx_j", C.c_void_p), ("dx_h", C.c_void_p), ("dsig", C.c_void_p), ("sig", C.c_void_p),
+                ("sigb", C.c_void_p), ("sigt", C.c_void_p), ("heightmap", C.c_void_p), ("dy", C.c_double),
+                ("ptop", C.c_double)]
+
+
 (OP_ADV_U, OP_ADV_V, OP_GEO_GRAD_U, OP_GEO_GRAD_V, OP_ADV_GEO, OP_LAPLACIAN, OP_VISCOSITY, OP_DENSITY_FROM,
  OP_GEOPOTENTIAL_FROM, OP_TO_TRUE_TEMP, OP_TO_POTENTIAL_TEMP, OP_TO_DENSITY, OP_SCALING, OP_UNSCALING) = range(14)
 OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
@@ -97,6 +108,9 @@ SYMBOLS = {
                            C.POINTER(C.c_void_p * 4), C.POINTER(C.c_void_p * 4)]),
     "gcm_sw2d_op": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p]),
+    "gcm_pe25d_op": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p * 5),
+                               C.POINTER(C.c_void_p * 4)]),
+    "gcm_pe25d_op_last_error": (C.c_char_p, []),
     "gcm_ops_last_error": (C.c_char_p, []),
     "gcm_time_steps": (C.c_int, [_H, C.c_int, C.c_double, _dp, _dp]),
 }

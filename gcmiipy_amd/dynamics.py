@@ -87,3 +87,70 @@ def run(p, u, v, t, q, dt, geom, steps, callback=None, every=1):
         return _wrap_out(c.get_state(), units)
     finally:
         c.close()
+
+
+# ---- the operators the step is made of, one by one (dynamics.py:15-181), behind gcm_pe25d_op:
+# arrays in the reference's layout ([k, j, i]; p: [j, i]), SI magnitudes out
+def _op(kind, geom, ins, out_shapes):
+    import ctypes as C
+    from ._lib import lib, PeGeom
+    from .core import GcmError
+    L, H, W = geom.layers, geom.height, geom.width
+    shp3, shp2 = (L, H, W), (H, W)
+    arrs = [as_f64(strip(x)[0], shp2 if two_d else shp3, "operand") for x, two_d in ins]
+    tabs = [as_f64(np.asarray(strip(getattr(geom, k))[0], dtype=np.float64).reshape(-1), (n,), k)
+            for k, n in (("dx_j", H), ("dx_h", H), ("dsig", L), ("sig", L), ("sigb", L), ("sigt", L))]
+    hm = as_f64(strip(geom.heightmap)[0], shp2, "heightmap")
+    g = PeGeom(*[t.ctypes.data for t in tabs], hm.ctypes.data, scalar(geom.dy), scalar(geom.ptop))
+    outs = [np.empty(shp2 if two_d else shp3) for two_d in out_shapes]
+    pin = (C.c_void_p * 5)(*([a.ctypes.data for a in arrs] + [None] * (5 - len(arrs))))
+    pout = (C.c_void_p * 4)(*([o.ctypes.data for o in outs] + [None] * (4 - len(outs))))
+    rc = lib.gcm_pe25d_op(kind, W, H, L, C.addressof(g), C.byref(pin), C.byref(pout))
+    if rc != _lib.OK:
+        msg = lib.gcm_pe25d_op_last_error().decode()
+        if rc == _lib.ERR_ARG:
+            raise ValueError(msg)
+        raise GcmError("gcmcore error %d: %s" % (rc, msg))
+    return outs[0] if len(outs) == 1 else tuple(outs)
+
+
+def calc_pu(p, u, geom=None): return _op(_lib.PEOP_CALC_PU, _need(geom, u, p), ((p, True), (u, False)), (False,))    # :15-17
+def calc_pv(p, v, geom=None): return _op(_lib.PEOP_CALC_PV, _need(geom, v, p), ((p, True), (v, False)), (False,))    # :20-22
+def un_pu(pu, p, geom=None): return _op(_lib.PEOP_UN_PU, _need(geom, pu, p), ((pu, False), (p, True)), (False,))     # :25-27
+def un_pv(pv, p, geom=None): return _op(_lib.PEOP_UN_PV, _need(geom, pv, p), ((pv, False), (p, True)), (False,))     # :30-32
+def aflux(pu, pv, geom): return _op(_lib.PEOP_AFLUX, geom, ((pu, False), (pv, False)), (True, False))              # :35-46
+def advec_sig(sd, q, geom): return _op(_lib.PEOP_ADVEC_SIG, geom, ((sd, False), (q, False)), (False,))             # :49-52
+
+
+def advec_m_pu(p, u, v, pu, pv, geom):                                                                             # :55-108
+    return _op(_lib.PEOP_ADVEC_M_PU, geom, ((p, True), (u, False), (v, False), (pu, False), (pv, False)), (False, False))
+
+
+def compute_geopotential(p, t, geom):                                                                              # :111-143
+    return _op(_lib.PEOP_GEOPOTENTIAL, geom, ((p, True), (t, False)), (False,))
+
+
+def pgf(p, t, geom):                                                                                               # :147-171
+    return _op(_lib.PEOP_PGF, geom, ((p, True), (t, False)), (False, False, False, False))
+
+
+def advec_t(pu, pv, t, geom): return _op(_lib.PEOP_ADVEC_T, geom, ((pu, False), (pv, False), (t, False)), (False,))  # :174-181
+
+
+class _Shape:
+    """calc_pu / calc_pv / un_pu / un_pv take no geometry in the reference: the grid is the arrays' shape"""
+    def __init__(self, L, H, W):
+        self.layers, self.height, self.width = L, H, W
+        self.dx_j = self.dx_h = np.ones(H)
+        self.dsig = self.sig = self.sigb = self.sigt = np.ones(L)
+        self.heightmap = np.zeros((H, W))
+        self.dy, self.ptop = 1.0, 0.0
+
+
+def _need(geom, a3, a2):
+    if geom is not None:
+        return geom
+    s = np.shape(strip(a3)[0])
+    if len(s) != 3:
+        raise ValueError("expected a [k, j, i] array")
+    return _Shape(*s)

@@ -309,6 +309,26 @@ typedef enum {
 } gcm_sw2d_op_kind;
 int gcm_sw2d_op(int kind, int width, int height, double dx, double mu, const double *x0, const double *x1,
                 const double *x2, double *out);
+/* The operators of dynamics.py one by one (dynamics.py:15-181): host float64 arrays in the
+ * reference's layout, 3-D [layers][height][width], 2-D [height][width], periodic in i and j (and in
+ * k where the reference rolls k), geometry tables as geometry.gen_geometry builds them.  Inputs and
+ * outputs in the reference's argument / return order:
+ *   CALC_PU (p, u) -> pu            CALC_PV (p, v) -> pv         UN_PU (pu, p) -> u     UN_PV (pv, p) -> v
+ *   AFLUX (pu, pv) -> pit[2-D], sd  ADVEC_SIG (sd, q) -> dq      ADVEC_M_PU (p, u, v, pu, pv) -> dut, dvt
+ *   GEOPOTENTIAL (p, t) -> phi      PGF (p, t) -> pgfu, pgfv, phiu, phiv       ADVEC_T (pu, pv, t) -> dt   */
+typedef enum {
+    GCM_PEOP_CALC_PU = 0, GCM_PEOP_CALC_PV = 1, GCM_PEOP_UN_PU = 2, GCM_PEOP_UN_PV = 3, GCM_PEOP_AFLUX = 4,
+    GCM_PEOP_ADVEC_SIG = 5, GCM_PEOP_ADVEC_M_PU = 6, GCM_PEOP_GEOPOTENTIAL = 7, GCM_PEOP_PGF = 8, GCM_PEOP_ADVEC_T = 9
+} gcm_pe25d_op_kind;
+typedef struct {
+    const double *dx_j, *dx_h;                  /* [height]  geometry.py:136-137 */
+    const double *dsig, *sig, *sigb, *sigt;     /* [layers]                      */
+    const double *heightmap;                    /* [height][width] or NULL       */
+    double dy, ptop;
+} gcm_pe_geom;
+int gcm_pe25d_op(int kind, int width, int height, int layers, const gcm_pe_geom *g, const double *const in[5],
+                 double *const out[4]);
+const char *gcm_pe25d_op_last_error(void);
 /* flux_limiter.py on 1-D arrays of n cells (host arrays in/out; ip/im = np.roll by -1/+1,
  * coordinates_1d.py:25-30).  Results are BIT-identical to NumPy's, masks included: IEEE division,
  * no contraction.
