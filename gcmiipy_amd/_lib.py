@@ -33,7 +33,8 @@ class PeGeom(C.Structure):
 
 
 (OP_ADV_U, OP_ADV_V, OP_GEO_GRAD_U, OP_GEO_GRAD_V, OP_ADV_GEO, OP_LAPLACIAN, OP_VISCOSITY, OP_DENSITY_FROM,
- OP_GEOPOTENTIAL_FROM, OP_TO_TRUE_TEMP, OP_TO_POTENTIAL_TEMP, OP_TO_DENSITY, OP_SCALING, OP_UNSCALING) = range(14)
+ OP_GEOPOTENTIAL_FROM, OP_TO_TRUE_TEMP, OP_TO_POTENTIAL_TEMP, OP_TO_DENSITY, OP_SCALING, OP_UNSCALING,
+ OP_PE2D_ADVEC_P, OP_PE2D_DUT, OP_PE2D_DVT, OP_PE2D_PGF_U, OP_PE2D_PGF_V) = range(19)
 OK, ERR_ARG, ERR_HIP, ERR_NODEVICE, ERR_STATE, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 
 _dp = C.POINTER(C.c_double)

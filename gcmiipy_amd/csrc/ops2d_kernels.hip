@@ -249,6 +249,41 @@ __global__ __launch_bounds__(256) void sw2d_op_kernel(int kind, int W, int H, co
         case GCM_OP_TO_DENSITY: r = x1[o] / (kRd * x0[o]); break;                 // :22-24
         case GCM_OP_SCALING: r = x0[o] * x1[o] * dx * dx; break;                  // matsumo_temp.py:28-30
         case GCM_OP_UNSCALING: r = x1[o] / (x0[o] * dx * dx); break;              // :33-35
+        case GCM_OP_PE2D_ADVEC_P:                                                 // no_limits_2d.py:41-44 (pu, pv)
+            r = (x0[o] - x0[ow]) / dx + (x1[o] - x1[on]) / dx;
+            break;
+        case GCM_OP_PE2D_DUT:
+        case GCM_OP_PE2D_DVT: {                                                   // advec_m(p, u, v, dx), :47-76
+            const double *p = x0, *u = x1, *v = x2;
+            const auto P = [&](int jj, int ii) { return p[at2(jj, ii, H, W)]; };
+            const auto U = [&](int jj, int ii) { return u[at2(jj, ii, H, W)]; };
+            const auto V = [&](int jj, int ii) { return v[at2(jj, ii, H, W)]; };
+            const auto jphp = [&](int jj, int ii) { return (P(jj, ii) + P(jj + 1, ii)) / 2; };
+            const auto p_mid = [&](int jj, int ii) { return (jphp(jj, ii) + jphp(jj, ii + 1)) / 2; };          // iph(jph(p))
+            if (kind == GCM_OP_PE2D_DUT) {
+                const auto puum = [&](int jj, int ii) { const double a = (U(jj, ii) + U(jj, ii - 1)) / 2; return a * a * P(jj, ii); };
+                const auto puvm = [&](int jj, int ii) {
+                    return ((U(jj, ii) + U(jj - 1, ii)) / 2) * ((V(jj - 1, ii) + V(jj - 1, ii + 1)) / 2) * p_mid(jj - 1, ii);
+                };
+                r = (puum(j, i) - puum(j, i + 1)) / dx + (puvm(j, i) - puvm(j, i + 1)) / dx;
+            } else {
+                const auto pvvm = [&](int jj, int ii) { const double a = (V(jj, ii) + V(jj - 1, ii)) / 2; return a * a * P(jj, ii); };
+                const auto pvum = [&](int jj, int ii) {
+                    return p_mid(jj, ii - 1) * ((V(jj, ii) + V(jj, ii - 1)) / 2) * ((U(jj, ii - 1) + U(jj + 1, ii - 1)) / 2);
+                };
+                r = (pvvm(j, i) - pvvm(j + 1, i)) / dx + (pvum(j, i) - pvum(j, i + 1)) / dx;
+            }
+            break;
+        }
+        case GCM_OP_PE2D_PGF_U:
+        case GCM_OP_PE2D_PGF_V: {                                                 // pgf(p, t, dx), :79-92
+            const long o2 = kind == GCM_OP_PE2D_PGF_U ? oe : os;
+            const double ph = (x0[o] + x0[o2]) / 2;
+            const double tt = ((x1[o] + x1[o2]) / 2) * exner(ph, tab);            // to_true_temp(iph(t), iph(p))
+            const double rho = ph / (kRd * tt);
+            r = ph / rho * ((x0[o2] - x0[o]) / dx);
+            break;
+        }
         default: break;
     }
     out[o] = r;
@@ -342,11 +377,11 @@ int gcm_pe1d(int n, int nsteps, int half_only, double dt, double dx, const doubl
 
 int gcm_sw2d_op(int kind, int width, int height, double dx, double mu, const double *x0, const double *x1,
                 const double *x2, double *out) {
-    static const int nin[] = {2, 2, 1, 1, 3, 1, 1, 2, 2, 2, 2, 2, 2, 2};
-    if (kind < 0 || kind > GCM_OP_UNSCALING || width < 1 || height < 1 || !out || !x0 || (nin[kind] > 1 && !x1) ||
+    static const int nin[] = {2, 2, 1, 1, 3, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 2, 2};
+    if (kind < 0 || kind > GCM_OP_PE2D_PGF_V || width < 1 || height < 1 || !out || !x0 || (nin[kind] > 1 && !x1) ||
         (nin[kind] > 2 && !x2))
         return ops_fail(GCM_ERR_ARG, "gcm_sw2d_op: bad argument");
-    const bool uses_dx = kind <= GCM_OP_VISCOSITY || kind >= GCM_OP_SCALING;
+    const bool uses_dx = kind <= GCM_OP_VISCOSITY || kind >= GCM_OP_SCALING;      // (all of the no_limits_2d ones do)
     if (uses_dx && !(dx != 0.0)) return ops_fail(GCM_ERR_ARG, "gcm_sw2d_op: dx must be non-zero");
     if (gcm_device_count() < 1) return ops_fail(GCM_ERR_NODEVICE, "gcm_sw2d_op: no HIP device; no CPU fallback");
     const size_t n = (size_t)width * height;

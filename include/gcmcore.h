@@ -305,7 +305,12 @@ typedef enum {
     GCM_OP_TO_POTENTIAL_TEMP = 10,/* to_potential_temp(tt, p)                 :15-19                   */
     GCM_OP_TO_DENSITY = 11,       /* to_density(tt, p)                        :22-24                   */
     GCM_OP_SCALING = 12,          /* scaling(pa, t, dx)                       matsumo_temp.py:28-30    */
-    GCM_OP_UNSCALING = 13         /* unscaling(pb, tt, dx)                    :33-35                   */
+    GCM_OP_UNSCALING = 13,        /* unscaling(pb, tt, dx)                    :33-35                   */
+    GCM_OP_PE2D_ADVEC_P = 14,     /* advec_p(pu, pv, dx)                      no_limits_2d.py:41-44    */
+    GCM_OP_PE2D_DUT = 15,         /* advec_m(p, u, v, dx)[0]                  :47-76                   */
+    GCM_OP_PE2D_DVT = 16,         /* advec_m(p, u, v, dx)[1]                                           */
+    GCM_OP_PE2D_PGF_U = 17,       /* pgf(p, t, dx)[0]                         :79-92                   */
+    GCM_OP_PE2D_PGF_V = 18        /* pgf(p, t, dx)[1]                                                  */
 } gcm_sw2d_op_kind;
 int gcm_sw2d_op(int kind, int width, int height, double dx, double mu, const double *x0, const double *x1,
                 const double *x2, double *out);
