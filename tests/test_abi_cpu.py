@@ -53,6 +53,29 @@ def test_no_cpu_fallback_without_device():
         matsumo_scheme(z, z, z + 1, 1.0, 1.0)
 
 
+def test_operator_drop_ins_fail_loudly_without_device():
+    """every per-operator entry point (no handle: host arrays in, host arrays out) refuses to run
+    without a gfx950 device -- no NumPy fallback hides behind the reference's function names"""
+    from gcmiipy_amd import _lib
+    if _lib.lib.gcm_device_count() != 0:
+        pytest.skip("a HIP device is present")
+    from gcmiipy_amd import (two_d, flux_limiter, no_limits, matsuno_c_grid, matsumo_temp, viscosity, temperature,
+                             dynamics, no_limits_2d, geometry, low_pass)
+    from gcmiipy_amd.core import GcmError
+    a = np.ones((4, 6))
+    a3 = np.ones((2, 4, 6))
+    geom = geometry.gen_geometry(4, 6, 2)
+    calls = [lambda: two_d.gradient(a, (1.0, 1.0), 0), lambda: two_d.pgf_one_d(1.0, 1.0, a),
+             lambda: flux_limiter.calc_r(np.ones(8)), lambda: no_limits.matsuno_timestep(*[np.ones(8)] * 4, 1.0, 1.0),
+             lambda: matsuno_c_grid.advection_of_velocity_u(a, a, 1.0), lambda: matsumo_temp.density_from(a, a),
+             lambda: viscosity.finite_laplacian_2d(a, 1.0), lambda: temperature.to_true_temp(a, a),
+             lambda: dynamics.aflux(a3, a3, geom), lambda: dynamics.calc_pu(a, a3),
+             lambda: no_limits_2d.advec_m(a, a, a, 1.0), lambda: low_pass.arakawa_1977(a3, geom)]
+    for f in calls:
+        with pytest.raises(GcmError, match="no HIP device"):
+            f()
+
+
 def test_argument_validation_mirrors_reference_asserts():
     import gcmiipy_amd as g
     from gcmiipy_amd.matsuno_c_grid import matsumo_scheme
