@@ -524,6 +524,7 @@ __global__ __launch_bounds__(512) void pe_pit2d_kernel(PeArgsT<T> a) {
 // columns that are multiples of 64, filled before the main loop.
 template <typename T>
 struct PgfCol { T rho0, rho1, phi0, phi1; };
+constexpr int kPgfBatch = 4;
 
 template <typename T, int MAXR, unsigned MASK = 0>
 __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
@@ -555,33 +556,39 @@ __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
     const T sg0 = a.sig[k0], sg1 = two ? a.sig[k1] : sg0;
     const T ptop = a.ptop;
     T *out = a.pgfu + o0;
+    const int wpad = (W + 63) / 64 * 64;
     __syncthreads();
-    const auto column = [=](int i) {
-        const T pc = sp[i];
-        const T tp0 = pc * sg0 + ptop, tp1 = pc * sg1 + ptop;
+    // what a column needs from memory, and what is made of it
+    struct Raw { T pc, pe, t0, t1, ph; };
+    const auto request = [=](int i_raw) {
+        const int i = i_raw < W ? i_raw : W - 1;
+        const int ie = i + 1 == W ? 0 : i + 1;
+        return Raw{sp[i], sp[ie], st0[i], st1[i], phi0[i]};
+    };
+    const auto column_of = [=](const Raw &r) {
+        const T tp0 = r.pc * sg0 + ptop, tp1 = r.pc * sg1 + ptop;
         const T ex0 = exner(tp0, tab), ex1 = exner(tp1, tab);
-        const T t0 = st0[i], t1 = st1[i];
         PgfCol<T> c;
-        c.rho0 = rho_of(tp0, t0, ex0);
-        c.rho1 = rho_of(tp1, t1, ex1);
-        c.phi0 = phi0[i];
-        c.phi1 = phi_up(c.phi0, t0, t1, ex0, ex1);
+        c.rho0 = rho_of(tp0, r.t0, ex0);
+        c.rho1 = rho_of(tp1, r.t1, ex1);
+        c.phi0 = r.ph;
+        c.phi1 = phi_up(c.phi0, r.t0, r.t1, ex0, ex1);
         return c;
     };
-    for (int e = threadIdx.x; e * 64 < W; e += blockDim.x) edge[e] = column(e * 64);
+    for (int e = threadIdx.x; e * 64 < W; e += blockDim.x) edge[e] = column_of(request(e * 64));
     __syncthreads();
     // every lane of a wave goes through the loop body (DPP reads its neighbour lane): columns past
     // the end are clamped and not stored
     const int lane = threadIdx.x & 63;
-    const auto value = [&](int i_raw) {
+    const auto value = [&](int i_raw, const Raw &r) {
         const int i = i_raw < W ? i_raw : W - 1;
         const int ie = i + 1 == W ? 0 : i + 1;
-        const PgfCol<T> c = column(i);
+        const PgfCol<T> c = column_of(r);
         PgfCol<T> e;
         e.rho0 = from_east(c.rho0); e.rho1 = from_east(c.rho1);
         e.phi0 = from_east(c.phi0); e.phi1 = from_east(c.phi1);
         if (lane == 63 || ie == 0) e = edge[ie >> 6];
-        const T pc = sp[i], pe = sp[ie];
+        const T pc = r.pc, pe = r.pe;
         const T iphp = (pc + pe) * T(0.5);
         const T gradp = (pe - pc) * inv_dxj;
         const T phiu0 = iphp * ((e.phi0 - c.phi0) * inv_dxj);                      // dynamics.py:159
@@ -590,16 +597,27 @@ __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
         const T pgu1 = ((sg1 * pc + sg1 * pe) * T(0.5)) * rcp((c.rho1 + e.rho1) * T(0.5)) * gradp;
         return mkv<V>(pgu0 + phiu0, two ? pgu1 + phiu1 : T(0.0));
     };
+    // the columns of a thread are requested kPgfBatch at a time (one memory latency per batch instead
+    // of one per column), then worked off
+    const auto sweep = [&](const auto &sink) {
+        for (int base = threadIdx.x; base < wpad; base += kPgfBatch * (int)blockDim.x) {
+            Raw r[kPgfBatch];
+#pragma unroll
+            for (int m = 0; m < kPgfBatch; ++m) r[m] = request(min(base + m * (int)blockDim.x, wpad - 1));
+#pragma unroll
+            for (int m = 0; m < kPgfBatch; ++m) {
+                const int i = base + m * (int)blockDim.x;
+                const V v = value(min(i, wpad - 1), r[m]);
+                if (i < W) sink(i, v);
+            }
+        }
+    };
     const auto store = [=](int i, V v) {
         out[i] = v.x;
         if (two) out[W + i] = v.y;
     };
-    const int wpad = (W + 63) / 64 * 64;
     if (a.filter && W > 1) {
-        for (int i = threadIdx.x; i < wpad; i += blockDim.x) {
-            const V v = value(i);
-            if (i < W) x[i] = v;
-        }
+        sweep([x](int i, V v) { x[i] = v; });
         __syncthreads();
         if (MAXR > 0) {
             const auto from_x = [x](int i, int) { return x[i]; };
@@ -609,10 +627,7 @@ __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
             for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, res[i]);
         }
     } else {
-        for (int i = threadIdx.x; i < wpad; i += blockDim.x) {
-            const V v = value(i);
-            if (i < W) store(i, v);
-        }
+        sweep(store);
     }
 }
 
