@@ -142,19 +142,6 @@ __global__ __launch_bounds__(512) void pe_spu_filter_loop_kernel(PeArgsT<T> a, i
     const int jg = wrapi(a.row0 + j, a.Hg);
     // LDS: the complex row, then iph(sp) of the row and the row's filter multiplier / W
     T *pe = (T *)(x + W), *sl = pe + W;
-    {
-        const T *sp = a.sp + ix.r2(j), *S = a.smul + (long)jg * (W / 2 + 1);
-        const T inv_n = T(1.0) / (T)W;
-        for (int i = threadIdx.x; i < W; i += blockDim.x) {
-            const int ie = i + 1 == W ? 0 : i + 1;
-            pe[i] = (sp[i] + sp[ie]) * T(0.5);                   // dynamics.py:15-17
-            if (i <= W / 2) sl[i] = S[i] * inv_n;
-        }
-    }
-    FilterConsts<T> c;
-    filter_consts<T>(c, a.tw, a.cplan, W);
-    c.s = sl;
-    __syncthreads();
     const int nb0 = W / (a.cplan.r1[0] * a.cplan.r2[0]);
     const T *su_row = a.su + ix.r3(j);
     T *out_row = a.spu + ix.r3(j);
@@ -169,7 +156,35 @@ __global__ __launch_bounds__(512) void pe_spu_filter_loop_kernel(PeArgsT<T> a, i
             in[m] = mkv<V>(s0[i], s1[i]);
         }
     };
-    request(pb0, threadIdx.x);
+    request(pb0, threadIdx.x);                                   // travels while the row's tables are made
+    {
+        // (four columns of a thread requested at a time: one memory latency per batch, not per column)
+        const T *sp = a.sp + ix.r2(j), *S = a.smul + (long)jg * (W / 2 + 1);
+        const T inv_n = T(1.0) / (T)W;
+        constexpr int kB = 4;
+        for (int base = threadIdx.x; base < W; base += kB * (int)blockDim.x) {
+            T pc[kB], pn[kB], sm[kB];
+#pragma unroll
+            for (int m = 0; m < kB; ++m) {
+                const int i = min(base + m * (int)blockDim.x, W - 1);
+                pc[m] = sp[i];
+                pn[m] = sp[i + 1 == W ? 0 : i + 1];
+                sm[m] = S[min(i, W / 2)];
+            }
+#pragma unroll
+            for (int m = 0; m < kB; ++m) {
+                const int i = base + m * (int)blockDim.x;
+                if (i < W) {
+                    pe[i] = (pc[m] + pn[m]) * T(0.5);            // dynamics.py:15-17
+                    if (i <= W / 2) sl[i] = sm[m] * inv_n;
+                }
+            }
+        }
+    }
+    FilterConsts<T> c;
+    filter_consts<T>(c, a.tw, a.cplan, W);
+    c.s = sl;
+    __syncthreads();
     for (int pair = pb0; pair < pb1; ++pair) {
         const int k0 = 2 * pair;
         const bool two = k0 + 1 < L;
