@@ -1295,20 +1295,31 @@ struct RadArgsT {
 // step, and the fp32 variant then differs from fp64 only by the rounding of what it stores.
 // One thread per column.  The long-wave absorption needs the upwelling flux from BELOW a level and
 // the downwelling flux from ABOVE it, two opposite scans: the bottom-up scan parks one value per
-// level (the absorbed upwelling) and the top-down scan recomputes the level's emission from theta,
-// which it reads a second time (the first read is a few tens of KB back: it comes from the caches).
+// level (the absorbed upwelling) and the top-down scan recomputes the level's emission from theta
+// (LMAX > 0: kept in registers from the one up-front request of the column; LMAX == 0: read again).
 // LMAX > 0: L <= LMAX and the parked column lives in registers (loops unrolled); LMAX == 0: any L,
 // parked in LDS, park[L][threads].  The kernel reads theta and writes it (apply) or dTdt (diagnostic);
 // nothing else goes through HBM.
 constexpr int kRadThreads = 128;
+constexpr int kRadTabs = 7;      // per level: tlw, clw_b_div, swfac, sig, dsig, 1 - tlw, G / (Cp dsig)
 template <typename T, int LMAX>
 __global__ __launch_bounds__(kRadThreads) void pe_radiation_kernel(PeArgsT<T> a, RadArgsT<T> r, T *t_inout) {
     __shared__ double tab[kExnerTabDoubles];
+    __shared__ double lev[kRadTabs][LMAX > 0 ? LMAX : 1];
     extern __shared__ unsigned char rad_park_raw[];
     for (int n = threadIdx.x; n < kExnerTabDoubles; n += kRadThreads) tab[n] = a.exner_tab[n];
+    const int W = a.W, L = a.L;
+    if (LMAX > 0) {
+        // the level tables go to LDS (read from global memory inside the scans, every one of their
+        // waits would also wait for the theta column still in flight)
+        for (int k = threadIdx.x; k < LMAX; k += kRadThreads) {
+            const int kk = min(k, L - 1);
+            lev[0][k] = r.tlw[kk]; lev[1][k] = r.clw_b_div[kk]; lev[2][k] = r.swfac[kk];
+            lev[3][k] = (double)a.sig[kk]; lev[4][k] = (double)a.dsig[kk];
+        }
+    }
     __syncthreads();
     constexpr double kSolar = 1.3608 * 1000.0, kSb = 5.67e-8, kCg = 1.13e6;   // constants.py:59,71,25
-    const int W = a.W, L = a.L;
     double *p_lwb = (double *)rad_park_raw + threadIdx.x;
     double lwb_reg[LMAX > 0 ? LMAX : 1];
     const int i = blockIdx.x * kRadThreads + threadIdx.x;
@@ -1316,6 +1327,13 @@ __global__ __launch_bounds__(kRadThreads) void pe_radiation_kernel(PeArgsT<T> a,
     if (i >= W) return;
     const int jg = wrapi(a.row0 + j, a.Hg);
     const long c3 = (long)j * L * W + i, c2 = (long)j * W + i;
+    // LMAX > 0: the whole theta column is requested before any of it is used (one memory latency per
+    // column instead of one per level and scan) and kept: the top-down scan does not read it again
+    T tcol[LMAX > 0 ? LMAX : 1];
+    if (LMAX > 0) {
+#pragma unroll
+        for (int k = 0; k < LMAX; ++k) tcol[k] = t_inout[c3 + (long)min(k, L - 1) * W];
+    }
     const double pc = (double)a.p[c2], gt = r.gt[c2], ptop = (double)a.ptop;
     // zenith_angle, grey_solar.py:49-65 (declination 0)
     const double pa = r.lon[i] + r.hour_angle;
@@ -1324,13 +1342,19 @@ __global__ __launch_bounds__(kRadThreads) void pe_radiation_kernel(PeArgsT<T> a,
     const double S = (1 - r.albedo) * Sc * r.csw_top[0];
     const double g2 = gt * gt;
     const double U_s = 1 * kSb * (g2 * g2);
+    const auto tlw = [&](int k) { return LMAX > 0 ? lev[0][k] : r.tlw[k]; };
+    const auto clw = [&](int k) { return LMAX > 0 ? lev[1][k] : r.clw_b_div[k]; };
+    const auto swf = [&](int k) { return LMAX > 0 ? lev[2][k] : r.swfac[k]; };
+    const auto sig = [&](int k) { return LMAX > 0 ? lev[3][k] : (double)a.sig[k]; };
+    const auto dsg = [&](int k) { return LMAX > 0 ? lev[4][k] : (double)a.dsig[k]; };
     // true temperature and emission of one level (to_true_temp; grey_solar.py emission)
     const auto emission = [&](int k, double *tt_out) {
-        const double tp = pc * (double)a.sig[k] + ptop;
-        const double tt = (double)t_inout[c3 + (long)k * W] * exner(tp, tab);
+        const double tp = pc * sig(k) + ptop;
+        const double th = LMAX > 0 ? (double)tcol[LMAX > 0 ? k : 0] : (double)t_inout[c3 + (long)k * W];
+        const double tt = th * exner(tp, tab);
         const double t2 = tt * tt;
         *tt_out = tt;
-        return (1 - r.tlw[k]) * kSb * (t2 * t2);
+        return (1 - tlw(k)) * kSb * (t2 * t2);
     };
     double B = 0.0, up = 0.0;
 #pragma unroll(LMAX > 0 ? LMAX : 2)
@@ -1338,11 +1362,11 @@ __global__ __launch_bounds__(kRadThreads) void pe_radiation_kernel(PeArgsT<T> a,
         if (LMAX > 0 && k >= L) break;
         double tt;
         const double em = emission(k, &tt);
-        B += em * r.clw_b_div[k];
-        const double lwb = up * (1 - r.tlw[k]);
+        B += em * clw(k);
+        const double lwb = up * (1 - tlw(k));
         if (LMAX > 0) lwb_reg[k] = lwb;
         else p_lwb[k * kRadThreads] = lwb;
-        up = up * r.tlw[k] + em;
+        up = up * tlw(k) + em;
     }
     const double dtg = (B + S - U_s) / kCg / (.1);
     if (r.apply) r.gt[c2] = gt + dtg * r.dt;
@@ -1355,14 +1379,14 @@ __global__ __launch_bounds__(kRadThreads) void pe_radiation_kernel(PeArgsT<T> a,
         const long o = c3 + (long)k * W;
         double tt;
         const double em = emission(k, &tt);
-        const double lwa = down * (1 - r.tlw[k]);
-        down = down * r.tlw[k] + em;
-        const double U_n = r.clw_b_div[k] * U_s * (1 - r.tlw[k]);
-        const double S_n = r.swfac[k] * Sc;
+        const double lwa = down * (1 - tlw(k));
+        down = down * tlw(k) + em;
+        const double U_n = clw(k) * U_s * (1 - tlw(k));
+        const double S_n = swf(k) * Sc;
         const double lwb = LMAX > 0 ? lwb_reg[k] : p_lwb[k * kRadThreads];
-        const double dTdt = (U_n + S_n - 2 * em + lwa + lwb) * (kG / (kCp * pc * (double)a.dsig[k]));
+        const double dTdt = (U_n + S_n - 2 * em + lwa + lwb) * (kG / (kCp * pc * dsg(k)));
         if (r.apply) {
-            const double tp = pc * (double)a.sig[k] + ptop;
+            const double tp = pc * sig(k) + ptop;
             const double tt_n = tt + dTdt * r.dt;
             t_inout[o] = (T)(tt_n * rcp(exner(tp, tab)));          // to_potential_temp
         } else {
