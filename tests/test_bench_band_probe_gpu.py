@@ -1,0 +1,64 @@
+"""bench.py's multi-rank path on the one GPU of the test box: run_workload for a 2-way split of the
+C3 grid with the loopback exchange standing in for the RCCL ring and a one-rank stand-in for
+torch.distributed -- the band runs through gcm_band_run (deep halo, k = 4), both exchange sequences
+are timed (gcm_set_band_overlap) and one is kept, exactly the code the driver's --gpus N run executes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _OneRank:
+    """the collectives bench.py issues, for a world of one process"""
+    class ReduceOp:
+        MAX = "max"
+
+    def barrier(self):
+        pass
+
+    def all_reduce(self, t, op=None):
+        return t
+
+
+def test_run_workload_band_path_and_overlap_probe(monkeypatch):
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from gcmiipy_amd.bands import LoopbackExchange
+    monkeypatch.setattr(bench, "SETTLE_S", 0.01)
+    monkeypatch.setattr(bench, "MIN_TIMED_S", 0.02)
+    cx = bench.Ctx()
+    cx.torch, cx.dist = torch, _OneRank()
+    cx.rank, cx.world, cx.local, cx.backend = 0, 2, 0, "nccl"
+    cx.ring, cx.exchange, cx.stuck, cx.exchange_fallback = LoopbackExchange(), "loopback (test)", False, None
+    torch.cuda.set_device(0)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        res = bench.run_workload(cx, "c3", 8, 4, want_kernel=False)
+    assert res["n_gpus"] == 2 and res["ms_per_step"] > 0 and np.isfinite(res["value"])
+    probe = res["band_overlap_probe_ms_per_step"]
+    assert probe["chosen"] in ("plain", "overlap") and probe["plain"] > 0 and probe["overlap"] > 0
+    assert "diagnostics" in res and res["diagnostics"]["band_ms_per_step_local_exchange"] > 0
+
+
+def test_run_workload_pe25d_band_path(monkeypatch):
+    """the same for the 2.5-D workload: an 8-way split's band (90 rows: 3-row K4 groups, edge rows in
+    level segments, exchange behind the pack on the second stream) through bench.run_workload"""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from gcmiipy_amd.bands import LoopbackExchange
+    monkeypatch.setattr(bench, "SETTLE_S", 0.01)
+    monkeypatch.setattr(bench, "MIN_TIMED_S", 0.02)
+    cx = bench.Ctx()
+    cx.torch, cx.dist = torch, _OneRank()
+    cx.rank, cx.world, cx.local, cx.backend = 3, 8, 0, "nccl"
+    cx.ring, cx.exchange, cx.stuck, cx.exchange_fallback = LoopbackExchange(), "loopback (test)", False, None
+    torch.cuda.set_device(0)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        res = bench.run_workload(cx, "c4", 4, 2, want_kernel=False)
+    assert res["n_gpus"] == 8 and res["ms_per_step"] > 0 and np.isfinite(res["value"])
+    assert res["band_overlap_probe_ms_per_step"] is None
