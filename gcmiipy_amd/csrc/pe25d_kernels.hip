@@ -522,12 +522,28 @@ __global__ __launch_bounds__(512) void pe_pit2d_kernel(PeArgsT<T> a) {
     const T inv_dxj = a.inv_dxj[jg], inv_dy = a.inv_dy;
     const T *spn = a.sp + ix.r2(j - 1), *sps = a.sp + ix.r2(j + 1);
     const T *cvc = a.scs_v + ix.r2(j), *cvn = a.scs_v + ix.r2(j - 1);
-    for (int i = threadIdx.x; i < W; i += blockDim.x) {
-        const int iw = i == 0 ? W - 1 : i - 1;
-        const T jph_c = (sp[i] + sps[i]) * T(0.5), jph_n = (spn[i] + sp[i]) * T(0.5);  // jph(sp) at j, j-1
-        const T pit = (fx[i] - fx[iw]) * inv_dxj + (cvc[i] * jph_c - cvn[i] * jph_n) * inv_dy;
-        a.pit[ix.r2(j) + i] = pit;
-        a.pn[ix.r2(j) + i] = a.p[ix.r2(j) + i] - pit * a.dt;
+    // (four columns of a thread requested at a time: one memory latency per batch, not per column --
+    // on a band this workgroup's chain is on the stage's critical path)
+    constexpr int kB = 4;
+    const T *pb = a.p + ix.r2(j);
+    for (int base = threadIdx.x; base < W; base += kB * (int)blockDim.x) {
+        T xc[kB], xs[kB], xn[kB], vc[kB], vn[kB], pp[kB];
+#pragma unroll
+        for (int m = 0; m < kB; ++m) {
+            const int i = min(base + m * (int)blockDim.x, W - 1);
+            xc[m] = sp[i]; xs[m] = sps[i]; xn[m] = spn[i]; vc[m] = cvc[i]; vn[m] = cvn[i]; pp[m] = pb[i];
+        }
+#pragma unroll
+        for (int m = 0; m < kB; ++m) {
+            const int i = base + m * (int)blockDim.x;
+            if (i < W) {
+                const int iw = i == 0 ? W - 1 : i - 1;
+                const T jph_c = (xc[m] + xs[m]) * T(0.5), jph_n = (xn[m] + xc[m]) * T(0.5);  // jph(sp) at j, j-1
+                const T pit = (fx[i] - fx[iw]) * inv_dxj + (vc[m] * jph_c - vn[m] * jph_n) * inv_dy;
+                a.pit[ix.r2(j) + i] = pit;
+                a.pn[ix.r2(j) + i] = pp[m] - pit * a.dt;
+            }
+        }
     }
 }
 
