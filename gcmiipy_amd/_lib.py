@@ -21,6 +21,7 @@ ADV_UPWIND, ADV_FV_UPWIND, ADV_FV_PLAIN, ADV_VANLEER, ADV_MOMENTUM = range(5)
 DIAG_ANY_NAN, DIAG_MAX_U, DIAG_MEAN_P, DIAG_SUM_P, DIAG_MIN_U, DIAG_MAX_V, DIAG_MIN_V = range(7)
 DIAG_TV_P, DIAG_TV_U, DIAG_TV_V, DIAG_TV_T, DIAG_TV_Q = range(7, 12)
 FL_VAN_LEER, FL_CALC_R, FL_DONOR_FLUX, FL_DONOR_ADVECTION = range(4)
+OP1D_ADVEC_Q, OP1D_CALC_PU, OP1D_UN_PU, OP1D_ADVEC_P, OP1D_ADVEC_PU, OP1D_ADVEC_T, OP1D_PGF = range(7)
 (PEOP_CALC_PU, PEOP_CALC_PV, PEOP_UN_PU, PEOP_UN_PV, PEOP_AFLUX, PEOP_ADVEC_SIG, PEOP_ADVEC_M_PU, PEOP_GEOPOTENTIAL,
  PEOP_PGF, PEOP_ADVEC_T) = range(10)
 
@@ -112,6 +113,7 @@ SYMBOLS = {
     "gcm_pe25d_op": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p * 5),
                                C.POINTER(C.c_void_p * 4)]),
     "gcm_pe25d_op_last_error": (C.c_char_p, []),
+    "gcm_pe1d_op": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gcm_ops_last_error": (C.c_char_p, []),
     "gcm_time_steps": (C.c_int, [_H, C.c_int, C.c_double, _dp, _dp]),
 }

@@ -289,6 +289,42 @@ __global__ __launch_bounds__(256) void sw2d_op_kernel(int kind, int W, int H, co
     out[o] = r;
 }
 
+// The operators of the 1-D model one by one (no_limits.py:50-112) on a periodic line of n cells.
+__global__ __launch_bounds__(256) void pe1d_op_kernel(int kind, int n, const double *x0, const double *x1, const double *x2,
+                                                     double *out, double dx, const double *etab) {
+    __shared__ double tab[kExnerTabDoubles];
+    tab[threadIdx.x] = etab[threadIdx.x];
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int im = i == 0 ? n - 1 : i - 1, ip = i + 1 == n ? 0 : i + 1;
+    double r = 0.0;
+    switch (kind) {
+        case GCM_OP1D_ADVEC_Q:                                        // advec_q(u, q, dx), :50-62
+            r = ((((x1[i] + x1[ip]) / 2) * x0[i]) - (((x1[im] + x1[i]) / 2) * x0[im])) / dx;
+            break;
+        case GCM_OP1D_CALC_PU: r = x0[i] * ((x1[i] + x1[ip]) / 2); break;       // calc_pu(u, p), :65-67
+        case GCM_OP1D_UN_PU: r = x0[i] / ((x1[i] + x1[ip]) / 2); break;         // un_pu(pu, p), :69-70
+        case GCM_OP1D_ADVEC_P: r = (x0[i] - x0[im]) / dx; break;                // advec_p(pu, dx), :73-75
+        case GCM_OP1D_ADVEC_PU: {                                     // advec_pu(p, pu, u, dx), :78-92 (pu itself unused)
+            const double um = (x2[im] + x2[i]) / 2, up = (x2[i] + x2[ip]) / 2;
+            r = ((up * up) * ((x0[i] + x0[ip]) / 2) - (um * um) * x0[i]) / dx;
+            break;
+        }
+        case GCM_OP1D_ADVEC_T:                                        // advec_t(pu, t, dx), :95-97
+            r = (x0[i] * ((x1[i] + x1[ip]) / 2) - x0[im] * ((x1[im] + x1[i]) / 2)) / dx;
+            break;
+        case GCM_OP1D_PGF: {                                          // pgf(p, t, dx), :102-112
+            const double pph = (x0[i] + x0[ip]) / 2, tph = (x1[i] + x1[ip]) / 2;
+            const double rho = pph / (kRd * (tph * exner(pph, tab)));
+            r = pph / rho * ((x0[ip] - x0[i]) / dx);
+            break;
+        }
+        default: break;
+    }
+    out[i] = r;
+}
+
 thread_local std::string g_ops_error;
 int ops_fail(int code, const char *m) { g_ops_error = m; return code; }
 }  // namespace
@@ -396,6 +432,26 @@ int gcm_sw2d_op(int kind, int width, int height, double dx, double mu, const dou
                        d0, d1, d2, o, dx, mu, dtab);
     if (hipMemcpy(out, o, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
         return ops_fail(GCM_ERR_HIP, "gcm_sw2d_op: kernel or copy-back failed");
+    return GCM_OK;
+}
+
+int gcm_pe1d_op(int kind, int n, double dx, const double *x0, const double *x1, const double *x2, double *out) {
+    static const int nin[] = {2, 2, 2, 1, 3, 2, 2};
+    if (kind < 0 || kind > GCM_OP1D_PGF || n < 1 || !out || !x0 || (nin[kind] > 1 && !x1) || (nin[kind] > 2 && !x2))
+        return ops_fail(GCM_ERR_ARG, "gcm_pe1d_op: bad argument");
+    if (kind != GCM_OP1D_CALC_PU && kind != GCM_OP1D_UN_PU && !(dx != 0.0))
+        return ops_fail(GCM_ERR_ARG, "gcm_pe1d_op: dx must be non-zero");
+    if (gcm_device_count() < 1) return ops_fail(GCM_ERR_NODEVICE, "gcm_pe1d_op: no HIP device; no CPU fallback");
+    DevBuf mem;
+    double tab[kExnerTabDoubles];
+    build_exner_table(tab);
+    double *d0 = mem.get(n, x0), *d1 = nin[kind] > 1 ? mem.get(n, x1) : nullptr, *d2 = nin[kind] > 2 ? mem.get(n, x2) : nullptr,
+           *o = mem.get(n), *dtab = mem.get(kExnerTabDoubles, tab);
+    if (!d0 || (nin[kind] > 1 && !d1) || (nin[kind] > 2 && !d2) || !o || !dtab)
+        return ops_fail(GCM_ERR_HIP, "gcm_pe1d_op: device allocation failed");
+    hipLaunchKernelGGL(pe1d_op_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, kind, n, d0, d1, d2, o, dx, dtab);
+    if (hipMemcpy(out, o, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return ops_fail(GCM_ERR_HIP, "gcm_pe1d_op: kernel or copy-back failed");
     return GCM_OK;
 }
 

@@ -45,3 +45,25 @@ def run(p, u, t, q, dt, dx, steps):
     """`steps` Matsuno steps with the state resident on the device (the reference's test loops,
     no_limits.py:248-262, without the plotting)"""
     return _call(int(steps), False, dt, dx, (p, u, t, q))
+
+
+# ---- the operators the step is made of, one by one (no_limits.py:50-112): 1-D arrays, SI magnitudes out
+def _op1(kind, arrays, dx=1.0):
+    from . import _lib
+    a = [as_f64(strip(x)[0], name="operand") for x in arrays]
+    if a[0].ndim != 1:
+        raise ValueError("no_limits works on 1-D arrays (coordinates_1d.py)")
+    a = [as_f64(x, a[0].shape, "operand") for x in a] + [None] * (3 - len(a))
+    out = np.empty(a[0].shape)
+    ptr = lambda x: None if x is None else x.ctypes.data
+    _ops_check(lib.gcm_pe1d_op(kind, a[0].size, scalar(dx), ptr(a[0]), ptr(a[1]), ptr(a[2]), out.ctypes.data))
+    return out
+
+
+def advec_q(u, q, dx): return _op1(0, (u, q), dx)               # :50-62
+def calc_pu(u, p): return _op1(1, (u, p))                       # :65-67
+def un_pu(pu, p): return _op1(2, (pu, p))                       # :69-70
+def advec_p(pu, dx): return _op1(3, (pu,), dx)                  # :73-75
+def advec_pu(p, pu, u, dx): return _op1(4, (p, pu, u), dx)      # :78-92
+def advec_t(pu, t, dx): return _op1(5, (pu, t), dx)             # :95-97
+def pgf(p, t, dx): return _op1(6, (p, t), dx)                   # :102-112

@@ -350,6 +350,13 @@ int gcm_flux_limiter(int kind, int n, const double *q, const double *u, double d
  * (:150-152), `stage` ignored.  Arrays are {p, u, t, q}, host float64.                            */
 int gcm_pe1d(int n, int nsteps, int half_only, double dt, double dx, const double *const base[4],
              const double *const stage[4], double *const out[4]);
+/* ... and its operators one by one (no_limits.py:50-112), arguments in the reference's order:
+ * ADVEC_Q (u, q), CALC_PU (u, p), UN_PU (pu, p), ADVEC_P (pu), ADVEC_PU (p, pu, u), ADVEC_T (pu, t), PGF (p, t) */
+typedef enum {
+    GCM_OP1D_ADVEC_Q = 0, GCM_OP1D_CALC_PU = 1, GCM_OP1D_UN_PU = 2, GCM_OP1D_ADVEC_P = 3, GCM_OP1D_ADVEC_PU = 4,
+    GCM_OP1D_ADVEC_T = 5, GCM_OP1D_PGF = 6
+} gcm_pe1d_op_kind;
+int gcm_pe1d_op(int kind, int n, double dx, const double *x0, const double *x1, const double *x2, double *out);
 const char *gcm_ops_last_error(void);
 
 /* Timing helper for bench.py: runs nsteps steps bracketed by HIP events on the

@@ -399,6 +399,13 @@ def g9_oned():
     for _ in range(10):
         p, u, t, q = no_limits.matsuno_timestep(p, u, t, q, 100.0 * U.s, 70000 * U.m)
     out.update(p10=m(p), u10=m(u), t10=m(t), q10=m(q))
+    # the operators of the step one by one (no_limits.py:50-112), on the state after those 10 steps
+    DX1 = 70000 * U.m
+    pu1 = no_limits.calc_pu(u, p)
+    out.update(op_p=m(p), op_u=m(u), op_t=m(t), op_q=m(q), op_calc_pu=m(pu1), op_un_pu=m(no_limits.un_pu(pu1, p)),
+               op_advec_q=m(no_limits.advec_q(u, q, DX1)), op_advec_p=m(no_limits.advec_p(pu1, DX1)),
+               op_advec_pu=m(no_limits.advec_pu(p, pu1, u, DX1)), op_advec_t=m(no_limits.advec_t(pu1, t, DX1)),
+               op_pgf=m(no_limits.pgf(p, t, DX1)))
     # 161-cell upwind mass advection, 400 steps (test_oneD.py world_shape)
     n = 161
     V = np.full((1, n), 2.0) * MS

@@ -70,3 +70,28 @@ def test_units_and_errors():
         no_limits.matsuno_timestep(p.reshape(2, -1), u.reshape(2, -1), t.reshape(2, -1), q.reshape(2, -1), 900.0, 70000.0)
     with pytest.raises(ValueError):
         no_limits.matsuno_timestep(p, u, t, q, 900.0, 0.0)
+
+
+def test_operators_one_by_one_vs_golden_and_oracle():
+    """no_limits.py:50-112 operator by operator vs G9 (`op_*`: the reference on the state after 10 steps)
+    and vs the oracle on a ragged length"""
+    from gcmiipy_amd import no_limits as nl
+    from oracle import oned
+    d = golden("g9_oned")
+    p, u, t, q, dx = d["op_p"], d["op_u"], d["op_t"], d["op_q"], 70000.0
+    pu = nl.calc_pu(u, p)
+    assert rel_err(pu, d["op_calc_pu"]) < TOL and rel_err(nl.un_pu(d["op_calc_pu"], p), d["op_un_pu"]) < TOL
+    assert rel_err(nl.advec_p(d["op_calc_pu"], dx), d["op_advec_p"]) < 1e-9      # differences of ~1e5-sized fluxes
+    assert rel_err(nl.advec_pu(p, d["op_calc_pu"], u, dx), d["op_advec_pu"]) < 1e-9
+    assert rel_err(nl.advec_t(d["op_calc_pu"], t, dx), d["op_advec_t"]) < 1e-9
+    assert rel_err(nl.advec_q(u, q, dx), d["op_advec_q"]) < TOL
+    assert rel_err(nl.pgf(p, t, dx), d["op_pgf"]) < 1e-9
+    rng = np.random.default_rng(9)
+    n = 77
+    p, u = 9e4 + 1e3 * rng.random(n), 10 * rng.standard_normal(n)
+    t, q = 300 + rng.random(n), rng.random(n)
+    pu = oned.calc_pu(u, p)
+    for got, want in ((nl.advec_q(u, q, 5e4), oned.advec_q(u, q, 5e4)), (nl.calc_pu(u, p), pu), (nl.un_pu(pu, p), oned.un_pu(pu, p)),
+                      (nl.advec_p(pu, 5e4), oned.advec_p(pu, 5e4)), (nl.advec_pu(p, pu, u, 5e4), oned.advec_pu(p, pu, u, 5e4)),
+                      (nl.advec_t(pu, t, 5e4), oned.advec_t(pu, t, 5e4)), (nl.pgf(p, t, 5e4), oned.pgf(p, t, 5e4))):
+        assert rel_err(got, want) < TOL

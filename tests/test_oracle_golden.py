@@ -274,6 +274,15 @@ def test_g9_oned():
         st = oned.matsuno_timestep(*st, float(d["dt"]), float(d["dx"]))
     for k, x in zip("putq", st):
         same(x, d[k + "10"])
+    p, u, t, q = (d["op_" + k] for k in "putq")             # the operators one by one, no_limits.py:50-112
+    pu = oned.calc_pu(u, p)
+    same(pu, d["op_calc_pu"])
+    same(oned.un_pu(pu, p), d["op_un_pu"])
+    same(oned.advec_q(u, q, 70000.0), d["op_advec_q"])
+    same(oned.advec_p(pu, 70000.0), d["op_advec_p"])
+    same(oned.advec_pu(p, pu, u, 70000.0), d["op_advec_pu"])
+    same(oned.advec_t(pu, t, 70000.0), d["op_advec_t"])
+    same(oned.pgf(p, t, 70000.0), d["op_pgf"])
     qq = d["adv_q0"]
     V = np.full((1, 161), 2.0)
     for _ in range(400):
