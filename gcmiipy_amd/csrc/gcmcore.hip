@@ -1089,6 +1089,43 @@ int gcm_energy(gcm_handle *h, const double *area, int area_len, double *out4) {
     return rc;
 }
 
+// constants.get_total_variation (constants.py:105-108) of ANY host array viewed as [n_axis][n_inner]
+// (the roll is along axis 0), and the two reductions of constants.courant_number (:111-112), max and
+// mean, for callers that hold no handle.  out3 = {sum |x - roll(x, -1, 0)|, max x, mean x}.
+int gcm_array_stats(const double *x, long n_axis, long n_inner, double *out3) {
+    if (!x || !out3 || n_axis < 1 || n_inner < 1) return GCM_ERR_ARG;
+    if (gcm_device_count() < 1) {
+        g_create_error = "gcm_array_stats: no HIP device; no CPU fallback";
+        return GCM_ERR_NODEVICE;
+    }
+    const long n = n_axis * n_inner;
+    constexpr int nb = 256;
+    double *dx = nullptr, *dp = nullptr;
+    std::vector<double> part(8 * nb);
+    hipError_t e = hipMalloc((void **)&dx, sizeof(double) * (size_t)n);
+    if (e == hipSuccess) e = hipMalloc((void **)&dp, sizeof(double) * 8 * nb);
+    if (e == hipSuccess) e = hipMemcpy(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(tv_kernel<double>, dim3(nb), dim3(256), 0, nullptr, dx, 1L, n_axis, n_inner, 1, dp);
+        hipLaunchKernelGGL(diag_kernel<double>, dim3(nb), dim3(256), 0, nullptr, dx, n, dp + 4 * nb);
+        e = hipMemcpy(part.data(), dp, sizeof(double) * 8 * nb, hipMemcpyDeviceToHost);
+    }
+    if (dx) (void)hipFree(dx);
+    if (dp) (void)hipFree(dp);
+    if (e != hipSuccess) {
+        g_create_error = std::string("gcm_array_stats: ") + hipGetErrorString(e);
+        return GCM_ERR_HIP;
+    }
+    double tv = 0.0, mx = -INFINITY, sm = 0.0;
+    for (int b = 0; b < nb; ++b) {
+        tv += part[4 * b + 2];
+        mx = std::fmax(mx, part[4 * nb + 4 * b]);
+        sm += part[4 * nb + 4 * b + 2];
+    }
+    out3[0] = tv; out3[1] = mx; out3[2] = sm / (double)n;
+    return GCM_OK;
+}
+
 int gcm_stats(gcm_handle *h, const double *area, int area_len, double *out9) {
     if (!h || !area || !out9 || area_len < 1) return GCM_ERR_ARG;
     if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_stats: GCM_PE25D only");

@@ -164,6 +164,10 @@ typedef enum {
     GCM_DIAG_TV_P = 7, GCM_DIAG_TV_U = 8, GCM_DIAG_TV_V = 9, GCM_DIAG_TV_T = 10, GCM_DIAG_TV_Q = 11
 } gcm_diag_kind;
 int gcm_diag(gcm_handle *h, int kind, double *out);
+/* The reductions of constants.py for callers that hold no handle: a host float64 array viewed as
+ * [n_axis][n_inner] -> out3 = { get_total_variation (sum |x - roll(x, -1, 0)|, constants.py:105-108),
+ * max x, mean x (the two reductions of courant_number, :111-112) }.  Errors: gcm_last_error(NULL). */
+int gcm_array_stats(const double *x, long n_axis, long n_inner, double *out3);
 /* The whole STATS record of full_timestep (no_limits_2_5d.py:85-91) by ONE launch and ONE
  * synchronisation (GCM_PE25D, fp64, single band): out9 = u_max, u_min, v_max, v_min, ke, ate, geo,
  * total (calc_energy, :35-60; `area` as gcm_energy), count of NaNs in u and v.                   */

@@ -101,3 +101,21 @@ def test_fused_stats_equals_separate_reductions(g):
     s = c.stats(area)
     assert s["nans"] >= 1.0 and np.isnan(s["u_max"])
     c.close()
+
+
+def test_constants_reductions_without_a_handle():
+    """constants.get_total_variation / courant_number on plain arrays (gcm_array_stats) vs G1's `tv` /
+    `courant`, G2's `courant`, and NumPy on other shapes; the constants themselves vs the oracle's"""
+    from gcmiipy_amd import constants as c
+    from oracle import constants as oc, grid
+    for k in ("Rd", "Cp", "kappa", "P0", "standard_pressure", "standard_temperature", "G", "radius", "mu_air", "Rv"):
+        assert getattr(c, k) == getattr(oc, k), k
+    d2 = golden("g2_sw2d")
+    assert abs(c.courant_number(d2["p0"], d2["u0"], float(d2["dx"]), float(d2["dt"])) / float(d2["courant"]) - 1) < 1e-12
+    rng = np.random.default_rng(5)
+    for shape in ((11,), (5, 7), (3, 5, 7), (1, 9), (64, 130)):
+        q = rng.standard_normal(shape)
+        assert abs(c.get_total_variation(q) / grid.get_total_variation(q) - 1) < 1e-12 if q.shape[0] > 1 else c.get_total_variation(q) == 0.0
+    d1 = golden("g1_shifts")
+    assert abs(c.get_total_variation(d1["a2"]) / float(d1["tv"]) - 1) < 1e-12
+    assert abs(c.courant_number(8000 + d1["a2"], d1["a2"], 300e3, 300.0) / float(d1["courant"]) - 1) < 1e-12
