@@ -63,7 +63,7 @@ WORKLOADS = {
                     "(BASELINE configs[4])", 1440, 2880, 40, "PE25D", None, 40.0 + 16.0 / 40, 1.0),
 }
 PHYS_UTC0 = 6 * 3600.0
-ALSO = ("c2", "c3", "c4", "c4_f32")     # secondary workloads of the default run
+ALSO = ("c2", "c3", "c4", "c4_f32", "c5_phys")     # secondary workloads of the default run (c5_phys: N = 1 only)
 DX = 300e3
 
 
@@ -104,7 +104,7 @@ def cpu_baseline(name):
         phys = "phys" in name
         if H * W * L <= 30e6:
             # the configured grid itself (c4: 2 steps, ~10 s each on one core)
-            rows, nst, what = slice(0, H), 2, "%d full steps of the %dx%dx%d grid" % (2, W, H, L)
+            rows, nst, what = slice(0, H), 1, "%d full step of the %dx%dx%d grid" % (1, W, H, L)
             sg = og
         else:
             # bounded sample of the configured grid: a latitude strip of FULL width and depth (the cost of a
@@ -436,7 +436,8 @@ def bring_up_direct_rccl(cx, torch, dist):
     """The ghost rows go over RCCL called directly (gcmiipy_amd.rccl; the library posts the exchange
     itself, gcm_band_run).  Bringing that communicator up between devices cannot be rehearsed on the
     one-GPU development box, so every step is agreed on by ALL ranks through torch.distributed
-    collectives issued from the main thread in the same order everywhere -- a rank that fails early
+    collectives (a gloo group on the CPU, created before the bring-up) issued from the main thread in
+    the same order everywhere -- a rank that fails early
     cannot leave the others parked in a different collective:
       1. every rank loads librccl, rank 0 makes the unique id         -> all_reduce(MIN) of 'ok'
       2. the id travels as a 128-byte CUDA tensor                      -> broadcast
@@ -448,8 +449,10 @@ def bring_up_direct_rccl(cx, torch, dist):
     import threading
 
     def agree(flag):
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        # over the CPU (gloo) group: a bring-up thread that timed out may still sit inside
+        # ncclCommInitRank on this device, and a device collective beside it could deadlock
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=cx.cpu_group)
         return int(t.item()) == 1
 
     err, uid = None, None
@@ -491,6 +494,24 @@ def bring_up_direct_rccl(cx, torch, dist):
     print("bench.py: direct RCCL exchange unavailable (%s); using torch.distributed" % cx.exchange_fallback, file=sys.stderr)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD job
+    (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1) from a parent that has not
+    imported torch nor touched the GPU, pass the arguments through, let rank 0's JSON line go to the
+    inherited stdout and return the job's exit code.  Nothing is re-exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -501,6 +522,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--only", action="store_true", help="skip the secondary workloads under 'also'")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))                 # before torch is imported or the GPU touched
 
     import torch
     cx = Ctx()
@@ -533,21 +557,27 @@ def main():
         # does the barriers.  GCM_BENCH_EXCHANGE=torch keeps batch_isend_irecv.
         cx.ring, cx.exchange = dist, "torch.distributed batch_isend_irecv (%s)" % cx.backend
         cx.exchange_fallback = None
+        cx.cpu_group = dist.new_group(backend="gloo") if cx.backend == "nccl" else None
         if cx.backend == "nccl" and os.environ.get("GCM_BENCH_EXCHANGE", "rccl") == "rccl":
             bring_up_direct_rccl(cx, torch, dist)
+            # one verdict for the whole job: if a bring-up thread is stuck on ANY rank, every rank reports
+            # the fallback, keeps off the device collectives' path of that thread and exits non-zero
+            t = torch.tensor([1 if cx.stuck else 0], dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=cx.cpu_group)
+            cx.stuck = int(t.item()) == 1
 
     main_res = run_workload(cx, a.workload, a.steps, a.warmup, a.variant)
-    also = {}
+    also, cpu_cache = {}, {}
     if not a.only:
         for name in ALSO:
             if name == a.workload:
                 continue
             if cx.world > 1 and name == "c2":
                 continue                                   # 360 rows: not a multi-GPU workload
-            if cx.world > 1 and name == "c4_f32":
+            if cx.world > 1 and name in ("c4_f32", "c5_phys"):
                 continue
             # c2: the noise IC goes unstable (in the reference too) near step 1300
-            st, wu = {"c2": (600, 50), "c3": (100, 10), "c4": (16, 3), "c4_f32": (16, 3)}[name]
+            st, wu = {"c2": (600, 50), "c3": (100, 10), "c4": (16, 3), "c4_f32": (16, 3), "c5_phys": (6, 2)}[name]
             if cx.world > 1 and name == "c4":
                 st, wu = 60, 10                            # a band's step is a fraction of a millisecond
             r = run_workload(cx, name, st, wu, want_kernel=cx.world == 1)
@@ -556,6 +586,12 @@ def main():
                 if cx.rank == 0:
                     r["one_gpu_same_run"] = {"value": r1["value"], "ms_per_step": r1["ms_per_step"]}
                     r["speedup_vs_one_gpu"] = r["value"] / r1["value"]
+            if cx.world == 1 and not a.no_cpu:
+                # the oracle is float64 whatever the handle's storage type: c4_f32 is set beside c4's figure
+                base = name[:-4] if name.endswith("_f32") else name
+                if base not in cpu_cache:
+                    cpu_cache[base] = cpu_baseline(base)
+                r["cpu_baseline"] = cpu_cache[base]
             if cx.rank == 0:
                 also[name] = r
 
@@ -583,7 +619,7 @@ def main():
         if "device_copy_same_bytes" in main_res:
             out["device_copy_same_bytes"] = main_res["device_copy_same_bytes"]
         if cx.world == 1:
-            out["cpu_baseline"] = None if a.no_cpu else cpu_baseline(a.workload)
+            out["cpu_baseline"] = None if a.no_cpu else cpu_cache.get(a.workload) or cpu_baseline(a.workload)
         if also:
             out["also"] = also
     if cx.dist is not None:

@@ -37,7 +37,9 @@ struct gcm_handle {
     double *exner_tab = nullptr;
     int G = kGhost;          // ghost rows per side = 2 * steps between exchanges (2-D bands)
     int since_exchange = 0;  // steps taken on the current ghost rows
+    bool ghosts_current = false;  // 2-D bands: the current state's ghost rows were filled after its last step
     bool star_valid = false;
+    bool launch_refused = false;      // hipLaunchKernel of the fused step returned an error (reported by launch_status)
     hipStream_t comm = nullptr;       // gcm_comm_stream: owned, created on first request
     double *snap[GCM_NFIELDS] = {};   // gcm_snapshot: device copy of the state, ghost rows included
     int snap_since_exchange = 0;
@@ -277,6 +279,7 @@ int gcm_set_state(gcm_handle *h, const double *p, const double *u, const double 
                   const double *t, const double *q) {
     if (!h) return GCM_ERR_ARG;
     h->primed = false;                                    // gcm_band_run: the new state's ghost rows are not exchanged yet
+    h->ghosts_current = false;
     if (h->pe) return pe25d_set(h->pe, false, p, u, v, t, q, h->stream, &h->err);
     const double *src[GCM_NFIELDS] = {p, u, v, t, q};
     h->star_valid = false;
@@ -349,8 +352,22 @@ static Sw2dArgs base_args(gcm_handle *h, double dt) {
     return a;
 }
 
+// what the launches queued since the last check returned: the status hipLaunchKernel handed back for the
+// fused step (kept in the handle: step_rows has many callers) and the runtime's sticky last error
+static int launch_status(gcm_handle *h) {
+    const hipError_t e = hipGetLastError();
+    if (h->launch_refused) {
+        h->launch_refused = false;
+        return fail(h, GCM_ERR_HIP, std::string("sw2d fused kernel: launch refused") +
+                                        (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string()));
+    }
+    HIPCHK(h, e);
+    return GCM_OK;
+}
+
 static void swap_state(gcm_handle *h) {
     for (int f = 0; f < GCM_NFIELDS; ++f) std::swap(h->cur[f], h->nxt[f]);
+    h->ghosts_current = false;
 }
 
 static void tick(gcm_handle *h, hipStream_t s) {
@@ -419,7 +436,7 @@ static void step_rows(gcm_handle *h, double dt, int j0, int j1, hipStream_t s) {
         a.j0 = j0;
         a.j1 = j1;
         tick(h, s);
-        launch_sw2d_fused(a, temp, h->has[GCM_Q] ? h->cfg.tracer : 0, s);
+        if (!launch_sw2d_fused(a, temp, h->has[GCM_Q] ? h->cfg.tracer : 0, s)) h->launch_refused = true;
         tick(h, s);
     } else {
         // the predicted state is needed one row beyond the rows produced
@@ -470,8 +487,7 @@ int gcm_step(gcm_handle *h, int nsteps, double dt) {
         if (!h->wrap) ++h->since_exchange;
     }
     h->star_valid = false;
-    HIPCHK(h, hipGetLastError());
-    return GCM_OK;
+    return launch_status(h);
 }
 
 int gcm_step_interior(gcm_handle *h, double dt, void *stream) {
@@ -480,8 +496,7 @@ int gcm_step_interior(gcm_handle *h, double dt, void *stream) {
     if (h->wrap) return fail(h, GCM_ERR_STATE, "step_interior: handle is not a latitude band");
     if (h->G != kGhost) return fail(h, GCM_ERR_STATE, "step_interior: halo_steps > 1 steps through gcm_step");
     step_rows(h, dt, kGhost, h->H - kGhost, (hipStream_t)stream);
-    HIPCHK(h, hipGetLastError());
-    return GCM_OK;
+    return launch_status(h);
 }
 
 int gcm_step_boundary(gcm_handle *h, double dt, void *stream) {
@@ -497,8 +512,7 @@ int gcm_step_boundary(gcm_handle *h, double dt, void *stream) {
     }
     swap_state(h);
     h->star_valid = false;
-    HIPCHK(h, hipGetLastError());
-    return GCM_OK;
+    return launch_status(h);
 }
 
 int gcm_step_phase(gcm_handle *h, int phase, double dt, void *stream) {
@@ -544,8 +558,7 @@ int gcm_half_step(gcm_handle *h, int stage, double dt) {
         swap_state(h);
         h->star_valid = false;
     }
-    HIPCHK(h, hipGetLastError());
-    return GCM_OK;
+    return launch_status(h);
 }
 
 // ------------------------------------------------------------------ ghost rows
@@ -583,10 +596,12 @@ static int halo_run(gcm_handle *h, bool pack, void *north, void *south, void *st
     if (north) rc = halo_segments(h, pack, 0, north, &c);
     if (rc == GCM_OK && south) rc = halo_segments(h, pack, 1, south, &c);
     if (rc != GCM_OK) return rc;
-    if (!pack && !h->pe) h->since_exchange = 0;
+    if (!pack && !h->pe) {
+        h->since_exchange = 0;
+        if (south) h->ghosts_current = true;       // (the total variation reads the south ghost row only)
+    }
     launch_seg_copy(c, (hipStream_t)stream);
-    HIPCHK(h, hipGetLastError());
-    return GCM_OK;
+    return launch_status(h);
 }
 
 extern "C" {
@@ -646,6 +661,7 @@ int gcm_restore(gcm_handle *h) {
                                  hipMemcpyDeviceToDevice, h->stream));
     }
     h->since_exchange = h->snap_since_exchange;
+    h->ghosts_current = false;
     h->star_valid = false;
     h->primed = false;              // gcm_band_run: exchange the restored state's ghost rows first
     return GCM_OK;
@@ -941,8 +957,7 @@ int gcm_band_run(gcm_handle *h, int nsteps, double dt) {
         h->xch_inflight = false;
     }
     h->star_valid = false;
-    HIPCHK(h, hipGetLastError());
-    return GCM_OK;
+    return launch_status(h);
 }
 
 // ------------------------------------------------------------------ diagnostics
@@ -1029,6 +1044,11 @@ int gcm_diag(gcm_handle *h, int kind, double *out) {
         case GCM_DIAG_TV_P: case GCM_DIAG_TV_U: case GCM_DIAG_TV_V: case GCM_DIAG_TV_T: case GCM_DIAG_TV_Q:
             f = kind - GCM_DIAG_TV_P;
             if (!h->pe && !h->has[f]) return fail(h, GCM_ERR_ARG, "gcm_diag: the model has no such field");
+            // a 2-D band differences its last row against the south ghost row: that row must belong to
+            // the CURRENT state (bands exchange before a step, so after a step it is stale)
+            if (!h->pe && !h->wrap && !h->ghosts_current)
+                return fail(h, GCM_ERR_STATE, "gcm_diag: total variation on a latitude band needs the current state's "
+                                              "ghost rows (exchange them first: gcm_halo_pack2 / exchange / gcm_halo_unpack2)");
             break;
         case GCM_DIAG_ANY_NAN: case GCM_DIAG_MAX_U: case GCM_DIAG_MIN_U: f = GCM_U; break;
         case GCM_DIAG_MEAN_P: case GCM_DIAG_SUM_P: f = GCM_P; break;
@@ -1116,13 +1136,15 @@ int gcm_array_stats(const double *x, long n_axis, long n_inner, double *out3) {
         g_create_error = std::string("gcm_array_stats: ") + hipGetErrorString(e);
         return GCM_ERR_HIP;
     }
-    double tv = 0.0, mx = -INFINITY, sm = 0.0;
+    double tv = 0.0, mx = -INFINITY, sm = 0.0, nn = 0.0;
     for (int b = 0; b < nb; ++b) {
         tv += part[4 * b + 2];
         mx = std::fmax(mx, part[4 * nb + 4 * b]);
         sm += part[4 * nb + 4 * b + 2];
+        nn += part[4 * nb + 4 * b + 3];
     }
-    out3[0] = tv; out3[1] = mx; out3[2] = sm / (double)n;
+    // np.max propagates NaN (constants.py:111-112); fmax drops it, so the count decides
+    out3[0] = tv; out3[1] = nn > 0 ? NAN : mx; out3[2] = sm / (double)n;
     return GCM_OK;
 }
 

@@ -6,6 +6,7 @@
 //   gcm_pgf2d     pgf_c_grid_axis / pgf_c_grid / pgf_templess / pressure_at_edge (:210-274)
 // Host pointers in, host pointers out (the reference's call shape); the field stays on the
 // device for all `nsteps`.
+#include "dev_arena.h"
 #include "../../include/gcmcore.h"
 #include "gcm_math.h"
 #include "sw2d_kernels.h"
@@ -126,17 +127,7 @@ static void launch_axis(int scheme, const AdvArgs &a, dim3 g, dim3 b) {
 using namespace gcm;
 
 namespace {
-struct DevBuf {
-    std::vector<void *> v;
-    ~DevBuf() { for (void *p : v) (void)hipFree(p); }
-    double *get(size_t n, const double *src = nullptr) {
-        void *d = nullptr;
-        if (hipMalloc(&d, n * sizeof(double)) != hipSuccess) return nullptr;
-        v.push_back(d);
-        if (src && hipMemcpy(d, src, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-        return (double *)d;
-    }
-};
+using DevBuf = gcm::DevScratch;      // operands from the calling thread's grow-only arena (dev_arena.h)
 // flux_limiter.py:10-32 on a periodic 1-D array; one thread per cell.  IEEE division and no
 // contraction: the results (and so the b != 0 / u > 0 masks they carry) are NumPy's bit for bit.
 __global__ __launch_bounds__(256) void flux_limiter_kernel(int kind, int n, const double *q, const double *u,

@@ -3,6 +3,7 @@
 // (and in k where it rolls k).  The step kernels of pe25d_kernels.hip evaluate the same expressions
 // fused; these are the reference's call surface for them and the per-operator parity anchors
 // (golden g7).  One thread per cell, or per column for the two operators that scan the levels.
+#include "dev_arena.h"
 #include "../../include/gcmcore.h"
 #include "gcm_math.h"
 #include "sw2d_kernels.h"
@@ -134,17 +135,7 @@ using namespace gcm;
 
 namespace {
 thread_local std::string g_peop_error;
-struct Bufs {
-    std::vector<void *> v;
-    ~Bufs() { for (void *p : v) (void)hipFree(p); }
-    double *get(size_t n, const double *src = nullptr) {
-        void *d = nullptr;
-        if (hipMalloc(&d, n * sizeof(double)) != hipSuccess) return nullptr;
-        v.push_back(d);
-        if (src && hipMemcpy(d, src, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-        return (double *)d;
-    }
-};
+using Bufs = gcm::DevScratch;      // operands from the calling thread's grow-only arena (dev_arena.h)
 int peop_fail(int code, const char *msg) {
     g_peop_error = msg;
     return code;

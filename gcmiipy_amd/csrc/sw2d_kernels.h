@@ -33,7 +33,7 @@ void launch_sw2d_derive(const Sw2dArgs &a, hipStream_t s);            // p,t -> 
 void launch_tracer_axis(const Sw2dArgs &a, int axis, bool limit, const double *q_in,
                         double *q_out, hipStream_t s);
 // fused variant: predictor + corrector (+ both tracer passes) in one launch
-void launch_sw2d_fused(const Sw2dArgs &a, bool temp, int tracer, hipStream_t s);
+bool launch_sw2d_fused(const Sw2dArgs &a, bool temp, int tracer, hipStream_t s);   // false: the launch was refused
 int sw2d_fused_rows_per_band(int W, int H, bool temp, int tracer, bool wrap);
 // GCM_SW2D, single band, short bands (small grids): TWO steps in one launch; false if not applicable
 bool launch_sw2d_fused2(const Sw2dArgs &a, hipStream_t s);

@@ -566,14 +566,14 @@ int sw2d_fused_rows_per_band(int W, int H, bool temp, int tracer, bool wrap) {
     return (int)(rpb < 8 ? 8 : rpb);
 }
 
-void launch_sw2d_fused(const Sw2dArgs &a, bool temp, int tracer, hipStream_t s) {
-    if (a.j1 <= a.j0) return;
+bool launch_sw2d_fused(const Sw2dArgs &a, bool temp, int tracer, hipStream_t s) {
+    if (a.j1 <= a.j0) return true;
     const int strips = (a.W + kStripCols - 1) / kStripCols;
     const int bands = (a.j1 - a.j0 + a.rows_per_band - 1) / a.rows_per_band;
     dim3 g((unsigned)(((long)strips * bands + 7) / 8 * 8));  // 1-D, padded to 8 XCD groups
     Sw2dArgs arg = a;
     void *params[] = {&arg};
-    (void)hipLaunchKernel(fused_kernel_ptr(temp, tracer, a.wrap_j != 0, a.rows_per_band), g, dim3(64), params, 0, s);
+    return hipLaunchKernel(fused_kernel_ptr(temp, tracer, a.wrap_j != 0, a.rows_per_band), g, dim3(64), params, 0, s) == hipSuccess;
 }
 
 __global__ void copy_rows_kernel(double *dst, const double *src, long n) {

@@ -159,14 +159,17 @@ typedef enum {
     /* get_total_variation(field) = sum |q - roll(q, -1, 0)|  (constants.py:105-108), the monitor
      * run_2d_with_ft evaluates every step (two_d.py:334-338).  Axis 0 of the REFERENCE layout: rows
      * j for 2-D fields, levels k for the 3-D fields of GCM_PE25D.  On a latitude band the last row
-     * is differenced against the south ghost row (current after an exchange); the band sums add up
-     * to the global figure.                                                                       */
+     * is differenced against the south ghost row, which must belong to the CURRENT state: a 2-D band
+     * exchanges before a step, so after one the call fails with GCM_ERR_STATE until the ghost rows
+     * have been exchanged again (gcm_halo_pack2 / exchange / gcm_halo_unpack2); the band sums then
+     * add up to the global figure.                                                                */
     GCM_DIAG_TV_P = 7, GCM_DIAG_TV_U = 8, GCM_DIAG_TV_V = 9, GCM_DIAG_TV_T = 10, GCM_DIAG_TV_Q = 11
 } gcm_diag_kind;
 int gcm_diag(gcm_handle *h, int kind, double *out);
 /* The reductions of constants.py for callers that hold no handle: a host float64 array viewed as
  * [n_axis][n_inner] -> out3 = { get_total_variation (sum |x - roll(x, -1, 0)|, constants.py:105-108),
- * max x, mean x (the two reductions of courant_number, :111-112) }.  Errors: gcm_last_error(NULL). */
+ * max x, mean x (the two reductions of courant_number, :111-112) }; a NaN anywhere in x makes all
+ * three NaN, as np.max / np.mean / np.sum do.  Errors: gcm_last_error(NULL).                     */
 int gcm_array_stats(const double *x, long n_axis, long n_inner, double *out3);
 /* The whole STATS record of full_timestep (no_limits_2_5d.py:85-91) by ONE launch and ONE
  * synchronisation (GCM_PE25D, fp64, single band): out9 = u_max, u_min, v_max, v_min, ke, ate, geo,

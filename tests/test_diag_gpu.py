@@ -119,3 +119,53 @@ def test_constants_reductions_without_a_handle():
     d1 = golden("g1_shifts")
     assert abs(c.get_total_variation(d1["a2"]) / float(d1["tv"]) - 1) < 1e-12
     assert abs(c.courant_number(8000 + d1["a2"], d1["a2"], 300e3, 300.0) / float(d1["courant"]) - 1) < 1e-12
+
+
+def test_courant_number_propagates_nan():
+    """np.max(u) is NaN when u holds a NaN (constants.py:111-112): the stability monitor must not hide a
+    blown-up field behind fmax"""
+    from gcmiipy_amd import constants as c
+    rng = np.random.default_rng(6)
+    u = rng.standard_normal((33, 70))
+    p = 8000 + rng.standard_normal((33, 70))
+    assert np.isfinite(c.courant_number(p, u, 300e3, 300.0))
+    u[17, 3] = np.nan
+    assert np.isnan(c.courant_number(p, u, 300e3, 300.0))
+    assert np.isnan(c.get_total_variation(u))
+
+
+def test_band_total_variation_sums_to_global_and_needs_current_ghosts(g):
+    """GCM_DIAG_TV_* on latitude bands: the last row is differenced against the south ghost row, so the
+    band partials add up to the single domain's figure once the CURRENT state's ghost rows have been
+    exchanged -- and the call refuses (GCM_ERR_STATE) while they are stale, i.e. right after a step"""
+    import torch
+    from gcmiipy_amd.bands import split_rows
+    from test_bands_gpu import _exchange, _ic2d
+    H, W, nb = 37, 130, 3
+    f = _ic2d((H, W))
+    kw = dict(dx=300e3, tracer=g._lib.TRACER_VANLEER)
+    ref = g.Core(g._lib.SW2D_TEMP, W, H, **kw)
+    ref.set_state(**f)
+    cores = []
+    for r, (row0, n) in enumerate(split_rows(H, nb)):
+        c = g.Core(g._lib.SW2D_TEMP, W, n, nranks=nb, rank=r, global_height=H, row0=row0, **kw)
+        c.set_state(**{k: v[row0:row0 + n] for k, v in f.items()})
+        cores.append(c)
+    with pytest.raises(g.GcmError):
+        cores[0].total_variation(g._lib.P)            # fresh state: ghost rows never filled
+    for rnd in range(2):
+        _exchange(cores, torch)
+        for fld in (g._lib.P, g._lib.U, g._lib.Q):
+            want = ref.total_variation(fld)
+            got = sum(c.total_variation(fld) for c in cores)
+            assert abs(got / want - 1) < 1e-12, (rnd, fld, got, want)
+        ref.step(1, 300.0)
+        for c in cores:
+            c.step_interior(300.0)
+        for c in cores:
+            c.step_boundary(300.0)
+        with pytest.raises(g.GcmError):
+            cores[1].total_variation(g._lib.U)        # stepped: the ghost rows belong to the old state
+    ref.close()
+    for c in cores:
+        c.close()

@@ -95,3 +95,44 @@ def test_operators_one_by_one_vs_golden_and_oracle():
                       (nl.advec_p(pu, 5e4), oned.advec_p(pu, 5e4)), (nl.advec_pu(p, pu, u, 5e4), oned.advec_pu(p, pu, u, 5e4)),
                       (nl.advec_t(pu, t, 5e4), oned.advec_t(pu, t, 5e4)), (nl.pgf(p, t, 5e4), oned.pgf(p, t, 5e4))):
         assert rel_err(got, want) < TOL
+
+
+def test_run_1d_with_ft_vs_golden():
+    """the 1-D harness (just_units.py:298-340) driving the config-1 model: ten `ft(**state)` steps
+    reproduce G9's state after 10 steps; the variation series is get_total_variation of each state;
+    a blown-up field ends the run with False, as the reference's early exit does"""
+    from gcmiipy_amd import no_limits
+    from gcmiipy_amd.just_units import run_1d_with_ft
+    from oracle import grid
+    d = golden("g9_oned")
+    dt, dx = float(d["dt"]), float(d["dx"])
+
+    def ft(p, u, t, q):
+        return dict(zip("putq", no_limits.matsuno_timestep(p, u, t, q, dt, dx)))
+
+    hist = []
+    ok = run_1d_with_ft({k: d[k + "0"] for k in "putq"}, ft, steps=10, variation_key="q", history=hist)
+    assert ok is True and len(hist) == 11
+    last = run_1d_with_ft.last_state
+    for k in "putq":
+        assert rel_err(last[k], d[k + "10"]) < TOL, k
+    assert abs(hist[0] / grid.get_total_variation(d["q0"]) - 1) < 1e-12
+    assert abs(hist[-1] / grid.get_total_variation(d["q10"]) - 1) < 1e-9
+
+    calls = []
+
+    def bad(p, u, t, q):
+        calls.append(1)
+        q = np.array(q)
+        if len(calls) == 3:
+            q[5] = np.nan
+        return dict(p=p, u=u, t=t, q=q)
+
+    assert run_1d_with_ft({k: d[k + "0"] for k in "putq"}, bad, steps=10) is False and len(calls) == 3
+
+    def grow(p, u, t, q):
+        q = np.array(q)
+        q[::2] += 400.0
+        return dict(p=p, u=u, t=t, q=q)
+
+    assert run_1d_with_ft({k: d[k + "0"] for k in "putq"}, grow, steps=10) is False
