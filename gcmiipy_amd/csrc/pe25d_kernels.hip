@@ -17,261 +17,9 @@
 // it acts on both parts independently), multiplied by S[j][n] and transformed back.
 #include "pe25d_kernels.h"
 
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <type_traits>
-
-#include "fft_lds.h"
-#include "gcm_math.h"
-#include "sw2d_kernels.h"
+#include "pe25d_dev.h"
 
 namespace gcm {
-
-constexpr int kMaxSeg = 4;      // level segments of the update kernel (short bands)
-constexpr int kMaxEdgeCols = 96; // K3: columns that are multiples of 64 (W <= 5120 + rounding)
-// real-type specific pieces: reciprocal and (p/P0)**kappa (fp32: v_rcp_f32 is 1 ulp; powf)
-__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float exner(float p, const double *) { return __powf(p * 1e-5f, (float)kKappa); }
-
-template <typename T>
-struct PeArgsT {
-    using T2 = typename Vec2<T>::type;
-    // base (time n) and stage state, device layout, pointers at interior row 0
-    const T *p, *u, *v, *t, *q;
-    const T *sp, *su, *sv, *st, *sq;
-    T *op, *ou, *ov, *ot, *oq;
-    // intermediates
-    T *spu, *phi, *pgfu;              // 3-D (phi: even levels only, see rho_of / phi_up)
-    T *pit, *pn;                      // 2-D
-    // column sums sum_k dsig[k] u[k], sum_k dsig[k] v[k] of the stage state (own rows; see pe_pit2d_kernel)
-    // and where K4 leaves those of the state it writes (null: not kept)
-    T *scs_u, *scs_v, *ocs_u, *ocs_v;
-    T *part;                          // [nseg-1] 2-D slabs: conv summed from the top down to a segment boundary
-    // tables (device)
-    const T *inv_dxj, *inv_dxh;       // [Hg] reciprocals of geometry.py:136-137
-    const T *sig, *dsig, *inv_dsig, *sigb, *sigt;  // [L]
-    const T *heightmap;               // [Hg][W] (global rows) or null
-    const T *cor_u, *cor_v;           // [Hg] Coriolis factors or null (dynamics.py:82-92)
-    const T *smul;                    // [Hg][W/2+1] filter multiplier (low_pass.py:61-72)
-    const T2 *tw;                     // [W] exp(-2 pi i n / W)
-    const double *exner_tab;               // always float64 (gcm_math.h exner())
-    FftPlan plan;                          // generic ping-pong passes (fallback)
-    SuperPlan cplan;                       // composite-radix in-place passes
-    int W, H, L, Hg, row0;                 // local rows, global rows, first global row
-    int wrap;                              // 1: rows wrap modulo H (single band)
-    int filter;
-    int j0, j1;                            // rows to produce
-    int jb0, jb1;                          // second row range of the same launch (K4 edge rows), or empty
-    int nseg;                              // K4 marches the column in nseg level segments (1: whole column)
-    long part_stride;                      // elements per slab of `part`
-    T dt, inv_dy, ptop;
-};
-
-__device__ __forceinline__ int wrapi(int x, int n) {
-    x %= n;
-    return x < 0 ? x + n : x;
-}
-
-struct Idx {
-    int W, H, L, wrap;
-    __device__ __forceinline__ int jr(int j) const { return wrap ? wrapi(j, H) : j; }
-    __device__ __forceinline__ long r3(int j) const { return (long)jr(j) * L * W; }   // row slab
-    __device__ __forceinline__ long r2(int j) const { return (long)jr(j) * W; }
-};
-
-// ---------------------------------------------------------------- K1: spu = filter(su * iph(sp))
-constexpr int kFftThreads = 256;    // generic path; the composite path sizes the workgroup from its plan
-template <typename T, int MAXR, unsigned MASK = 0>
-__global__ __launch_bounds__(512) void pe_spu_filter_kernel(PeArgsT<T> a) {
-    using V = typename Vec2<T>::type;
-    extern __shared__ unsigned char lds_raw[];
-    V *x = (V *)lds_raw;
-    const Idx ix{a.W, a.H, a.L, a.wrap};
-    const int j = a.j0 + blockIdx.x;
-    const int k0 = 2 * blockIdx.y, k1 = k0 + 1;
-    const bool two = k1 < a.L;
-    const int W = a.W;
-    const T *sp = a.sp + ix.r2(j);
-    const T *su0 = a.su + ix.r3(j) + (long)k0 * W;
-    const T *su1 = su0 + W;
-    T *o0 = a.spu + ix.r3(j) + (long)k0 * W;
-    const auto load = [=](int i, int = 0) {
-        const int ie = i + 1 == W ? 0 : i + 1;
-        const T pe = (sp[i] + sp[ie]) * T(0.5);      // iph(p), dynamics.py:15-17
-        return mkv<V>(su0[i] * pe, two ? su1[i] * pe : T(0.0));
-    };
-    const auto store = [=](int i, V v) {
-        o0[i] = v.x;
-        if (two) o0[W + i] = v.y;
-    };
-    if (a.filter && W > 1) {
-        if (MAXR > 0) {
-            const int jg = wrapi(a.row0 + j, a.Hg);
-            filter_rows_composite<MAXR, MASK, T>(x, load, store, a.tw, a.cplan, W, a.smul + (long)jg * (W / 2 + 1));
-        } else {
-            for (int i = threadIdx.x; i < W; i += blockDim.x) x[i] = load(i);
-            __syncthreads();
-            const V *res = filter_rows<T>(x, x + W, a.tw, a.plan, a.smul + (long)wrapi(a.row0 + j, a.Hg) * (W / 2 + 1));
-            for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, res[i]);
-        }
-    } else {
-        for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, load(i));
-    }
-}
-
-// K1, looping form: the workgroup of (row, group of level pairs) filters its pairs one after the
-// other.  What the passes fetch from tables (their twiddles, the filter multiplier) and iph(sp) depend
-// on the thread and the row only and are fetched once; the su values of the NEXT pair are requested
-// before the current pair is transformed (two register sets that swap by name), so the only waits
-// left inside the loop are LDS round trips and barriers.
-// NIN: radix of the plan's first pass (inputs per thread) where the instantiation knows it, else MAXR
-template <typename T, int MAXR, unsigned MASK = 0, int NIN = MAXR>
-__global__ __launch_bounds__(512) void pe_spu_filter_loop_kernel(PeArgsT<T> a, int pairs_per_wg) {
-    using V = typename Vec2<T>::type;
-    extern __shared__ unsigned char lds_raw[];
-    V *x = (V *)lds_raw;
-    const Idx ix{a.W, a.H, a.L, a.wrap};
-    const int W = a.W, L = a.L;
-    const int j = a.j0 + blockIdx.x;
-    const int npairs = (L + 1) / 2;
-    const int pb0 = blockIdx.y * pairs_per_wg, pb1 = min(pb0 + pairs_per_wg, npairs);
-    if (pb0 >= pb1) return;                                      // uniform
-    const int jg = wrapi(a.row0 + j, a.Hg);
-    // LDS: the complex row, then iph(sp) of the row and the row's filter multiplier / W
-    T *pe = (T *)(x + W), *sl = pe + W;
-    const int nb0 = W / (a.cplan.r1[0] * a.cplan.r2[0]);
-    const T *su_row = a.su + ix.r3(j);
-    T *out_row = a.spu + ix.r3(j);
-    V in[NIN];
-    // unconditional requests (an odd L's last pair reads its single level twice; the copy is not stored)
-    const auto request = [&](int pair, int tid) {
-        const int k0 = 2 * pair;
-        const T *s0 = su_row + (long)k0 * W, *s1 = s0 + (k0 + 1 < L ? W : 0);
-#pragma unroll
-        for (int m = 0; m < NIN; ++m) {
-            const int i = min(tid + m * nb0, W - 1);
-            in[m] = mkv<V>(s0[i], s1[i]);
-        }
-    };
-    request(pb0, threadIdx.x);                                   // travels while the row's tables are made
-    {
-        // (four columns of a thread requested at a time: one memory latency per batch, not per column)
-        const T *sp = a.sp + ix.r2(j), *S = a.smul + (long)jg * (W / 2 + 1);
-        const T inv_n = T(1.0) / (T)W;
-        constexpr int kB = 4;
-        for (int base = threadIdx.x; base < W; base += kB * (int)blockDim.x) {
-            T pc[kB], pn[kB], sm[kB];
-#pragma unroll
-            for (int m = 0; m < kB; ++m) {
-                const int i = min(base + m * (int)blockDim.x, W - 1);
-                pc[m] = sp[i];
-                pn[m] = sp[i + 1 == W ? 0 : i + 1];
-                sm[m] = S[min(i, W / 2)];
-            }
-#pragma unroll
-            for (int m = 0; m < kB; ++m) {
-                const int i = base + m * (int)blockDim.x;
-                if (i < W) {
-                    pe[i] = (pc[m] + pn[m]) * T(0.5);            // dynamics.py:15-17
-                    if (i <= W / 2) sl[i] = sm[m] * inv_n;
-                }
-            }
-        }
-    }
-    FilterConsts<T> c;
-    filter_consts<T>(c, a.tw, a.cplan, W);
-    c.s = sl;
-    __syncthreads();
-    for (int pair = pb0; pair < pb1; ++pair) {
-        const int k0 = 2 * pair;
-        const bool two = k0 + 1 < L;
-        T *o0 = out_row + (long)k0 * W;
-        // The thread index and the base twiddles are made opaque per iteration: otherwise the index
-        // arithmetic of all passes and every power of the twiddles (loop invariants now) would be
-        // hoisted out of the loop and held in hundreds of registers.
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        FilterConsts<T> cc = c;
-#pragma unroll
-        for (int n = 0; n < 3; ++n) asm volatile("" : "+v"(cc.w[n].x), "+v"(cc.w[n].y));
-        const auto first = [&](int i, int m) {
-            const T p = pe[i];
-            return mkv<V>(in[m < NIN ? m : 0].x * p, in[m < NIN ? m : 0].y * p);
-        };
-        // the next pair's su goes into the same registers as soon as the first pass has read them,
-        // and is in flight during the other passes
-        const auto after_first = [&]() { request(min(pair + 1, pb1 - 1), tid); };
-        const auto store = [=](int i, V v) {
-            o0[i] = v.x;
-            if (two) o0[W + i] = v.y;
-        };
-        filter_rows_hoisted<MAXR, MASK, T>(x, first, after_first, store, a.tw, a.cplan, W, cc, tid);
-    }
-}
-
-// The update kernel may march a column in several level segments (short latitude bands: more,
-// shorter workgroups).  Segment s covers levels [seg_lo(s), seg_lo(s+1)); the running sum of conv
-// from the top that sigma-dot needs (dynamics.py:42) then starts from a partial sum that
-// pe_pit_kernel leaves at every segment boundary.  Both kernels accumulate through these two
-// functions with explicit fma, so that the partial sums are bit-identical to what an unsplit march
-// has at that level and the result does not depend on the number of segments.
-__device__ __forceinline__ int seg_lo(int s, int nseg, int L) { return (int)((long)s * L / nseg); }
-// acc + ((fx_hi - fx_lo) / dx + (sv_hi jph_hi - sv_lo jph_lo) / dy) dsig; the meridional flux
-// products are formed in here: handed over as values, one kernel might fuse them into the
-// difference and the other not
-template <typename T>
-__device__ __forceinline__ T conv_acc(T acc, T fx_hi, T fx_lo, T inv_dx, T sv_hi, T jph_hi, T sv_lo, T jph_lo,
-                                      T inv_dy, T dsg) {
-    const T dy = fma(sv_hi, jph_hi, -(sv_lo * jph_lo));
-    return fma(fma(fx_hi - fx_lo, inv_dx, dy * inv_dy), dsg, acc);
-}
-template <typename T>
-__device__ __forceinline__ T sd_of(T rc, T pit, T sgb) { return fma(-pit, sgb, rc); }
-// kmh(q) sd: the flux of advec_sig (dynamics.py:50) through the face between two levels, a rounded
-// product (no contraction), so that it can be carried from the level above instead of recomputed
-template <typename T>
-__device__ __forceinline__ T face_flux_v(T q_a, T q_b, T sd) {
-#pragma clang fp contract(off)
-    return ((q_a + q_b) * T(0.5)) * sd;
-}
-
-// Density and geopotential are NOT kept in HBM level by level.  pe_geopot_kernel stores phi on
-// the even levels only (the anchors); the filter kernel K3 and the update kernel K4 rebuild rho on
-// every level and phi on the odd levels from the stage theta they read anyway, through the two
-// helpers below.  Contraction is off inside them, so that the three kernels round identically:
-// phi is then one well-defined field, whichever kernel evaluates it and however K4's level march
-// is segmented.
-//   rho = tp / (Rd tt), tt = t (tp/P0)**kappa                       dynamics.py:122-126
-//   phi[k] = phi[k-1] + Cp kph(t)[k-1] (pk[k-1] - pk[k])            dynamics.py:128-134 (cumsum)
-template <typename T>
-__device__ __forceinline__ T rho_of(T tp, T t, T ex) {
-#pragma clang fp contract(off)
-    const T tt = t * ex;
-    return tp * rcp(T(kRd) * tt);
-}
-template <typename T>
-__device__ __forceinline__ T stp_of(T t_lo, T t_hi, T ex_lo, T ex_hi) {
-#pragma clang fp contract(off)
-    return T(kCp) * ((t_lo + t_hi) * T(0.5)) * (ex_lo - ex_hi);
-}
-template <typename T>
-__device__ __forceinline__ T add_rn(T a, T b) {
-#pragma clang fp contract(off)
-    return a + b;
-}
-template <typename T>
-__device__ __forceinline__ T phi_up(T phi_lo, T t_lo, T t_hi, T ex_lo, T ex_hi) {
-#pragma clang fp contract(off)
-    const T stp = stp_of(t_lo, t_hi, ex_lo, ex_hi);
-    return phi_lo + stp;
-}
-// value of the wave's lane+1 (column i+1), fp32 flavour of gcm_math.h's from_east
-__device__ __forceinline__ float from_east(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
-}
 
 // ---------------------------------------------------------------- K2: column kernels
 // K2a pe_geopot_kernel: rho, phi from the stage theta and surface pressure (compute_geopotential);
@@ -445,17 +193,6 @@ __global__ __launch_bounds__(256) void pe_part_kernel(PeArgsT<T> a) {
     }
 }
 
-// ---------------------------------------------------------------- K2b', the 2-D form of pit
-// The filter is linear and iph(sp), jph(sp) do not depend on the level, so
-//   pit = sum_k dsig[k] conv[k] = d_i( filter(iph(sp) U) ) / dx + d_j( jph(sp) V ) / dy,
-//   U = sum_k dsig[k] su[k], V = sum_k dsig[k] sv[k]:
-// one filtered ROW per latitude instead of a second pass over the 3-D spu and sv (the sum is
-// reassociated: pit moves by a few ulp of its largest term, far inside the 1e-10 of the state).
-// K4 leaves U and V of the state it writes (cs_acc per level, k = L-1 .. 0); rows it does not own --
-// a band's ghost rows -- are summed by pe_colsum_kernel from the 3-D winds in the same order with the
-// same fma, so a band and the single domain see the same bits.
-template <typename T>
-__device__ __forceinline__ T cs_acc(T acc, T x, T dsg) { return fma(x, dsg, acc); }
 template <typename T>
 __device__ __forceinline__ T column_sum(const T *col, const T *dsig, int L, int W) {
     // eight levels requested at a time, then added in order (a load per iteration waits a memory
@@ -486,743 +223,6 @@ __global__ __launch_bounds__(256) void pe_colsum_kernel(PeArgsT<T> a) {
     const int j = jrel < na ? a.j0 + jrel : a.jb0 + (jrel - na);
     a.scs_u[ix.r2(j) + i] = column_sum(a.su + ix.r3(j) + i, a.dsig, a.L, W);
     a.scs_v[ix.r2(j) + i] = column_sum(a.sv + ix.r3(j) + i, a.dsig, a.L, W);
-}
-// one workgroup per row j of [j0, j1): pit and p_n = p - pit dt (dynamics.py:38-40,194)
-template <typename T, int MAXR, unsigned MASK = 0>
-__global__ __launch_bounds__(512) void pe_pit2d_kernel(PeArgsT<T> a) {
-    using V = typename Vec2<T>::type;
-    extern __shared__ unsigned char lds_raw[];
-    V *x = (V *)lds_raw;
-    const Idx ix{a.W, a.H, a.L, a.wrap};
-    const int W = a.W;
-    T *fx = (T *)(x + (MAXR > 0 ? 1 : 2) * W);                  // the filtered row, after the transform's workspace
-    const int j = a.j0 + blockIdx.x;
-    const int jg = wrapi(a.row0 + j, a.Hg);
-    const T *sp = a.sp + ix.r2(j);
-    const T *cu = a.scs_u + ix.r2(j);
-    const auto load = [=](int i, int = 0) {
-        const int ie = i + 1 == W ? 0 : i + 1;
-        const T pe = (sp[i] + sp[ie]) * T(0.5);                  // iph(p), dynamics.py:15-17
-        return mkv<V>(cu[i] * pe, T(0.0));
-    };
-    const auto store = [=](int i, V v) { fx[i] = v.x; };
-    if (a.filter && W > 1) {
-        if (MAXR > 0) {
-            filter_rows_composite<MAXR, MASK, T>(x, load, store, a.tw, a.cplan, W, a.smul + (long)jg * (W / 2 + 1));
-        } else {
-            for (int i = threadIdx.x; i < W; i += blockDim.x) x[i] = load(i);
-            __syncthreads();
-            const V *res = filter_rows<T>(x, x + W, a.tw, a.plan, a.smul + (long)jg * (W / 2 + 1));
-            for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, res[i]);
-        }
-    } else {
-        for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, load(i));
-    }
-    __syncthreads();
-    const T inv_dxj = a.inv_dxj[jg], inv_dy = a.inv_dy;
-    const T *spn = a.sp + ix.r2(j - 1), *sps = a.sp + ix.r2(j + 1);
-    const T *cvc = a.scs_v + ix.r2(j), *cvn = a.scs_v + ix.r2(j - 1);
-    // (four columns of a thread requested at a time: one memory latency per batch, not per column --
-    // on a band this workgroup's chain is on the stage's critical path)
-    constexpr int kB = 4;
-    const T *pb = a.p + ix.r2(j);
-    for (int base = threadIdx.x; base < W; base += kB * (int)blockDim.x) {
-        T xc[kB], xs[kB], xn[kB], vc[kB], vn[kB], pp[kB];
-#pragma unroll
-        for (int m = 0; m < kB; ++m) {
-            const int i = min(base + m * (int)blockDim.x, W - 1);
-            xc[m] = sp[i]; xs[m] = sps[i]; xn[m] = spn[i]; vc[m] = cvc[i]; vn[m] = cvn[i]; pp[m] = pb[i];
-        }
-#pragma unroll
-        for (int m = 0; m < kB; ++m) {
-            const int i = base + m * (int)blockDim.x;
-            if (i < W) {
-                const int iw = i == 0 ? W - 1 : i - 1;
-                const T jph_c = (xc[m] + xs[m]) * T(0.5), jph_n = (xn[m] + xc[m]) * T(0.5);  // jph(sp) at j, j-1
-                const T pit = (fx[i] - fx[iw]) * inv_dxj + (vc[m] * jph_c - vn[m] * jph_n) * inv_dy;
-                a.pit[ix.r2(j) + i] = pit;
-                a.pn[ix.r2(j) + i] = pp[m] - pit * a.dt;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------- K3: pgfu = filter(pgu + phiu)
-// The workgroup of (row, level pair k0 = 2 b, k1 = k0 + 1) rebuilds rho on both levels and phi on
-// the odd one from theta (see rho_of / phi_up); phi[k0] is the anchor pe_geopot_kernel stored.
-// Column i + 1 comes from the next lane (DPP); where the next column belongs to another wave
-// (lane 63, and the row's last column, which wraps to 0) it comes from a small LDS table of the
-// columns that are multiples of 64, filled before the main loop.
-template <typename T>
-struct PgfCol { T rho0, rho1, phi0, phi1; };
-constexpr int kPgfBatch = 4;
-
-template <typename T, int MAXR, unsigned MASK = 0>
-__global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
-    using V = typename Vec2<T>::type;
-    extern __shared__ unsigned char lds_raw[];
-    __shared__ double tab[kExnerTabDoubles];
-    __shared__ PgfCol<T> edge[kMaxEdgeCols];
-    V *x = (V *)lds_raw;
-    for (int n = threadIdx.x; n < kExnerTabDoubles; n += blockDim.x) tab[n] = a.exner_tab[n];
-    const Idx ix{a.W, a.H, a.L, a.wrap};
-    // 1-D grid of 8 x ceil(rows / 8) x pairs workgroups.  Consecutive workgroup ids go to the 8 XCDs
-    // in turn; within an XCD the level pairs of a row follow one another, so that the row's sp and
-    // filter multiplier (read by every pair) come from that XCD's L2 after the first.
-    const int npairs = (a.L + 1) / 2;
-    const int rows_per_xcd = gridDim.x / (8 * npairs);
-    const int l = blockIdx.x / 8;
-    const int jrel = (blockIdx.x % 8) * rows_per_xcd + l / npairs;
-    if (jrel >= a.j1 - a.j0) return;                             // padding (uniform)
-    const int j = a.j0 + jrel;
-    const int k0 = 2 * (l % npairs), k1 = k0 + 1;
-    const bool two = k1 < a.L;
-    const int W = a.W;
-    const int jg = wrapi(a.row0 + j, a.Hg);
-    const T inv_dxj = a.inv_dxj[jg];
-    const T *sp = a.sp + ix.r2(j);
-    const long o0 = ix.r3(j) + (long)k0 * W;
-    const T *phi0 = a.phi + o0;
-    const T *st0 = a.st + o0, *st1 = st0 + (two ? W : 0);
-    const T sg0 = a.sig[k0], sg1 = two ? a.sig[k1] : sg0;
-    const T ptop = a.ptop;
-    T *out = a.pgfu + o0;
-    const int wpad = (W + 63) / 64 * 64;
-    __syncthreads();
-    // what a column needs from memory, and what is made of it
-    struct Raw { T pc, pe, t0, t1, ph; };
-    const auto request = [=](int i_raw) {
-        const int i = i_raw < W ? i_raw : W - 1;
-        const int ie = i + 1 == W ? 0 : i + 1;
-        return Raw{sp[i], sp[ie], st0[i], st1[i], phi0[i]};
-    };
-    const auto column_of = [=](const Raw &r) {
-        const T tp0 = r.pc * sg0 + ptop, tp1 = r.pc * sg1 + ptop;
-        const T ex0 = exner(tp0, tab), ex1 = exner(tp1, tab);
-        PgfCol<T> c;
-        c.rho0 = rho_of(tp0, r.t0, ex0);
-        c.rho1 = rho_of(tp1, r.t1, ex1);
-        c.phi0 = r.ph;
-        c.phi1 = phi_up(c.phi0, r.t0, r.t1, ex0, ex1);
-        return c;
-    };
-    for (int e = threadIdx.x; e * 64 < W; e += blockDim.x) edge[e] = column_of(request(e * 64));
-    __syncthreads();
-    // every lane of a wave goes through the loop body (DPP reads its neighbour lane): columns past
-    // the end are clamped and not stored
-    const int lane = threadIdx.x & 63;
-    const auto value = [&](int i_raw, const Raw &r) {
-        const int i = i_raw < W ? i_raw : W - 1;
-        const int ie = i + 1 == W ? 0 : i + 1;
-        const PgfCol<T> c = column_of(r);
-        PgfCol<T> e;
-        e.rho0 = from_east(c.rho0); e.rho1 = from_east(c.rho1);
-        e.phi0 = from_east(c.phi0); e.phi1 = from_east(c.phi1);
-        if (lane == 63 || ie == 0) e = edge[ie >> 6];
-        const T pc = r.pc, pe = r.pe;
-        const T iphp = (pc + pe) * T(0.5);
-        const T gradp = (pe - pc) * inv_dxj;
-        const T phiu0 = iphp * ((e.phi0 - c.phi0) * inv_dxj);                      // dynamics.py:159
-        const T pgu0 = ((sg0 * pc + sg0 * pe) * T(0.5)) * rcp((c.rho0 + e.rho0) * T(0.5)) * gradp;   // dynamics.py:162-165
-        const T phiu1 = iphp * ((e.phi1 - c.phi1) * inv_dxj);
-        const T pgu1 = ((sg1 * pc + sg1 * pe) * T(0.5)) * rcp((c.rho1 + e.rho1) * T(0.5)) * gradp;
-        return mkv<V>(pgu0 + phiu0, two ? pgu1 + phiu1 : T(0.0));
-    };
-    // the columns of a thread are requested kPgfBatch at a time (one memory latency per batch instead
-    // of one per column), then worked off
-    const auto sweep = [&](const auto &sink) {
-        for (int base = threadIdx.x; base < wpad; base += kPgfBatch * (int)blockDim.x) {
-            Raw r[kPgfBatch];
-#pragma unroll
-            for (int m = 0; m < kPgfBatch; ++m) r[m] = request(min(base + m * (int)blockDim.x, wpad - 1));
-#pragma unroll
-            for (int m = 0; m < kPgfBatch; ++m) {
-                const int i = base + m * (int)blockDim.x;
-                const V v = value(min(i, wpad - 1), r[m]);
-                if (i < W) sink(i, v);
-            }
-        }
-    };
-    const auto store = [=](int i, V v) {
-        out[i] = v.x;
-        if (two) out[W + i] = v.y;
-    };
-    if (a.filter && W > 1) {
-        sweep([x](int i, V v) { x[i] = v; });
-        __syncthreads();
-        if (MAXR > 0) {
-            const auto from_x = [x](int i, int) { return x[i]; };
-            filter_rows_composite<MAXR, MASK, T>(x, from_x, store, a.tw, a.cplan, W, a.smul + (long)jg * (W / 2 + 1), true);
-        } else {
-            const V *res = filter_rows<T>(x, x + W, a.tw, a.plan, a.smul + (long)jg * (W / 2 + 1));
-            for (int i = threadIdx.x; i < W; i += blockDim.x) store(i, res[i]);
-        }
-    } else {
-        sweep(store);
-    }
-}
-
-// ---------------------------------------------------------------- K4: update
-// One thread per (j, i) column marching up the levels: the k-1 / k / k+1 values of the stage
-// winds, theta, q and sigma-dot rotate through registers, so only the horizontal neighbours
-// are loaded per level.  Tiles (row, 64-column block) are dealt to the 8 XCDs in contiguous
-// runs of rows (as sw2d_fused_kernel does): the blocks resident on one XCD work on adjacent
-// rows at about the same level, so the j+-1 re-reads hit that XCD's L2.
-constexpr int kUpdThreads = 64;   // one wave per workgroup: packs the rounds of a short band best (256: +2.5 %)
-template <typename T>
-__global__ __launch_bounds__(kUpdThreads) void pe_update_kernel(PeArgsT<T> a) {
-    __shared__ double tab[kExnerTabDoubles];
-    for (int n = threadIdx.x; n < kExnerTabDoubles; n += kUpdThreads) tab[n] = a.exner_tab[n];
-    __syncthreads();
-    const Idx ix{a.W, a.H, a.L, a.wrap};
-    const int W = a.W, L = a.L;
-    const int iblocks = (W + kUpdThreads - 1) / kUpdThreads;
-    const int per_xcd = gridDim.x / 8;
-    const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    // tile = ((row, level segment), column block); rows come from [j0, j1) then [jb0, jb1)
-    const int nseg = a.nseg;
-    const int rowseg = tile / iblocks;
-    const int jrel = rowseg / nseg, seg = rowseg - jrel * nseg;
-    const int na = a.j1 - a.j0;
-    if (jrel >= na + (a.jb1 - a.jb0)) return;                // padding tiles
-    const int j = jrel < na ? a.j0 + jrel : a.jb0 + (jrel - na);
-    const int i = (tile - rowseg * iblocks) * kUpdThreads + threadIdx.x;
-    if (i >= W) return;
-    const int iw = i == 0 ? W - 1 : i - 1, ie = i + 1 == W ? 0 : i + 1;
-    const int jg = wrapi(a.row0 + j, a.Hg);
-    const T inv_dxj = a.inv_dxj[jg], inv_dxh = a.inv_dxh[jg], inv_dy = a.inv_dy, dt = a.dt;
-    const long rc = ix.r3(j), rn = ix.r3(j - 1), rs = ix.r3(j + 1);
-    // surface pressure of the stage state on rows j-1 .. j+2 (level independent)
-    const T *spr = a.sp;
-    const long p_n = ix.r2(j - 1), p_c = ix.r2(j), p_s = ix.r2(j + 1), p_ss = ix.r2(j + 2);
-    const T sp_c = spr[p_c + i], sp_e = spr[p_c + ie];
-    const T sp_s = spr[p_s + i], sp_se = spr[p_s + ie], sp_ss = spr[p_ss + i];
-    const T sp_n = spr[p_n + i], sp_ne = spr[p_n + ie];
-    const T jph_c = (sp_c + sp_s) * T(0.5), jph_ce = (sp_e + sp_se) * T(0.5);     // jph(sp) at (j,i),(j,i+1)
-    const T jph_n = (sp_n + sp_c) * T(0.5), jph_ne = (sp_ne + sp_e) * T(0.5);     // at (j-1,i),(j-1,i+1)
-    const T jph_s = (sp_s + sp_ss) * T(0.5);                                   // at (j+1,i)
-    const T pb_c = a.p[p_c + i], pb_e = a.p[p_c + ie], pb_s = a.p[p_s + i];
-    const T iph_pb = (pb_c + pb_e) * T(0.5), jph_pb = (pb_c + pb_s) * T(0.5);
-    const T pn_c = a.pn[p_c + i], pn_e = a.pn[p_c + ie], pn_s = a.pn[p_s + i];
-    const T inv_pnu = rcp((pn_c + pn_e) * T(0.5)), inv_pnv = rcp((pn_c + pn_s) * T(0.5)), inv_pn = rcp(pn_c);
-    const bool pole_edge = jg == a.Hg - 1;
-    const bool coriolis = a.cor_u != nullptr;
-    const bool same = a.u == a.su;
-    const T cp_u = coriolis ? a.cor_u[jg] : T(0.0), cp_v = coriolis ? a.cor_v[jg] : T(0.0);
-    if (seg == 0) a.op[(long)j * W + i] = pn_c;
-
-    // The levels are marched from the top down, because sigma-dot is the top-down running sum of
-    // conv (dynamics.py:42: cumsum(conv[::-1])[::-1] - pit sigb, sd[0] = 0): it is rebuilt here,
-    // for this column and its east and south neighbours (iph(sd), jph(sd)), from the mass fluxes
-    // the momentum advection loads anyway, instead of being read back from HBM.
-    // Vertical window: level k+1 (p), k (c), k-1 (m).  kp()/km() wrap (coordinates_3d.py:55-60):
-    // level L is 0 and level -1 is L-1; both only ever meet sd[0] = T(0.)
-    // This workgroup marches levels [k_lo, k_hi) of its columns (the whole column if nseg == 1).
-    const T inv_dxj_s = a.inv_dxj[wrapi(a.row0 + j + 1, a.Hg)];
-    const T pit_c = a.pit[p_c + i], pit_e = a.pit[p_c + ie], pit_s = a.pit[p_s + i];
-    const int k_lo = seg_lo(seg, nseg, L), k_hi = seg_lo(seg + 1, nseg, L);
-    if (k_hi <= k_lo) return;
-    const long top = (long)(L - 1) * W;
-    const long kp0 = k_hi == L ? 0 : (long)k_hi * W;            // level k_hi; level L wraps to 0
-    const long kc0 = (long)(k_hi - 1) * W;
-    T su_p = a.su[rc + kp0 + i], sv_p = a.sv[rc + kp0 + i], st_p = a.st[rc + kp0 + i], sq_p = a.sq[rc + kp0 + i];
-    T su_c = a.su[rc + kc0 + i], sv_c = a.sv[rc + kc0 + i], st_c = a.st[rc + kc0 + i], sq_c = a.sq[rc + kc0 + i];
-    // running sums of conv from the top and sd at level k_hi: zero above the top level, else from
-    // the partial sums pe_pit_kernel left at this segment boundary
-    T rc_c = T(0.0), rc_e = T(0.0), rc_s = T(0.0);
-    T sd_cp = T(0.0), sd_ep = T(0.0), sd_sp = T(0.0);
-    if (k_hi < L) {
-        const T *part = a.part + (long)seg * a.part_stride;
-        const T sgb_hi = a.sigb[k_hi];
-        rc_c = part[p_c + i]; rc_e = part[p_c + ie]; rc_s = part[p_s + i];
-        sd_cp = sd_of(rc_c, pit_c, sgb_hi);
-        sd_ep = sd_of(rc_e, pit_e, sgb_hi);
-        sd_sp = sd_of(rc_s, pit_s, sgb_hi);
-    }
-    // rho and phi of this column and its south neighbour are rebuilt per level (rho_of / phi_up):
-    // an odd level k takes the anchor phi[k-1] that pe_geopot_kernel stored and steps up from it,
-    // and leaves the level k-1 values it needed (anchor, exner factors, the south theta) for the
-    // next, even, iteration -- two exner evaluations per level and column on average
-    const T ptop = a.ptop;
-    bool have_lo = false;
-    T lo_ex_c = T(0.0), lo_ex_s = T(0.0), lo_phi_c = T(0.0), lo_phi_s = T(0.0), lo_st_s = T(0.0);
-    for (int k = k_hi - 1; k >= k_lo; --k) {
-        const long kc = (long)k * W;
-        T su_m, sv_m, st_m, sq_m;
-        if (k > 0) {
-            const long kmo = kc - W;
-            su_m = a.su[rc + kmo + i]; sv_m = a.sv[rc + kmo + i]; st_m = a.st[rc + kmo + i]; sq_m = a.sq[rc + kmo + i];
-        } else {
-            su_m = a.su[rc + top + i]; sv_m = a.sv[rc + top + i]; st_m = a.st[rc + top + i]; sq_m = a.sq[rc + top + i];
-        }
-        // stage winds, horizontal neighbours
-        const T su_w = a.su[rc + kc + iw], su_e = a.su[rc + kc + ie];
-        const T su_n = a.su[rn + kc + i], su_s = a.su[rs + kc + i];
-        const T sv_w = a.sv[rc + kc + iw], sv_e = a.sv[rc + kc + ie];
-        const T sv_n = a.sv[rn + kc + i], sv_ne = a.sv[rn + kc + ie], sv_s = a.sv[rs + kc + i];
-        // mass fluxes: spu filtered (K1); spv = sv * jph(sp), dynamics.py:20-22
-        const T spu_c = a.spu[rc + kc + i], spu_w = a.spu[rc + kc + iw], spu_e = a.spu[rc + kc + ie];
-        const T spu_s = a.spu[rs + kc + i], spu_sw = a.spu[rs + kc + iw];
-        const T spv_c = sv_c * jph_c, spv_e = sv_e * jph_ce;
-        const T spv_n = sv_n * jph_n, spv_ne = sv_ne * jph_ne;
-        const T spv_s = sv_s * jph_s;
-        // ---- aflux, dynamics.py:35-46, at (j,i), (j,i+1), (j+1,i)
-        const T dsg = a.dsig[k], sgb = a.sigb[k];
-        T sd_c = T(0.0), sd_e = T(0.0), sd_s = T(0.0);           // sd[0] = 0, dynamics.py:44
-        if (k > 0) {
-            rc_c = conv_acc(rc_c, spu_c, spu_w, inv_dxj, sv_c, jph_c, sv_n, jph_n, inv_dy, dsg);
-            rc_e = conv_acc(rc_e, spu_e, spu_c, inv_dxj, sv_e, jph_ce, sv_ne, jph_ne, inv_dy, dsg);
-            rc_s = conv_acc(rc_s, spu_s, spu_sw, inv_dxj_s, sv_s, jph_s, sv_c, jph_c, inv_dy, dsg);
-            sd_c = sd_of(rc_c, pit_c, sgb);
-            sd_e = sd_of(rc_e, pit_e, sgb);
-            sd_s = sd_of(rc_s, pit_s, sgb);
-        }
-        // ---- advec_m_pu, dynamics.py:55-108
-        const T puum = ((su_c + su_w) * T(0.5)) * ((spu_c + spu_w) * T(0.5));
-        const T puup = ((su_e + su_c) * T(0.5)) * ((spu_e + spu_c) * T(0.5));
-        const T puvp = ((spv_c + spv_e) * T(0.5)) * ((su_c + su_s) * T(0.5));
-        const T puvm = ((spv_n + spv_ne) * T(0.5)) * ((su_n + su_c) * T(0.5));
-        const T pvvm = ((sv_c + sv_n) * T(0.5)) * ((spv_c + spv_n) * T(0.5));
-        const T pvvp = ((sv_s + sv_c) * T(0.5)) * ((spv_s + spv_c) * T(0.5));
-        const T pvup = ((sv_c + sv_e) * T(0.5)) * ((spu_c + spu_s) * T(0.5));
-        const T pvum = ((sv_w + sv_c) * T(0.5)) * ((spu_w + spu_sw) * T(0.5));
-        T cor_u = T(0.0), cor_v = T(0.0);                         // the reference adds a literal 0
-        if (coriolis) {                                          // dynamics.py:83-92
-            const T pu_at_pv = (((spu_c + spu_s) * T(0.5)) + ((spu_w + spu_sw) * T(0.5))) * T(0.5);    // imh(jph(pu))
-            const T pv_at_pu = (((spv_c + spv_n) * T(0.5)) + ((spv_e + spv_ne) * T(0.5))) * T(0.5);    // iph(jmh(pv))
-            cor_u = cp_u * -pv_at_pu;
-            cor_v = cp_v * pu_at_pv;
-        }
-        const T dut = (puum - puup) * inv_dxj + (puvm - puvp) * inv_dy + cor_u;
-        const T dvt = (pvvm - pvvp) * inv_dy + (pvum - pvup) * inv_dxh + cor_v;
-        // ---- pgf v-part, dynamics.py:160,167-169 (the u-part went through K3)
-        const T sg = a.sig[k];
-        T ex_c, ex_s, phi_c, phi_s, st_s;
-        if (have_lo) {
-            ex_c = lo_ex_c; ex_s = lo_ex_s; phi_c = lo_phi_c; phi_s = lo_phi_s; st_s = lo_st_s;
-        } else {
-            ex_c = exner(sp_c * sg + ptop, tab);
-            ex_s = exner(sp_s * sg + ptop, tab);
-            st_s = a.st[rs + kc + i];
-            phi_c = phi_s = T(0.0);
-            if ((k & 1) == 0) { phi_c = a.phi[rc + kc + i]; phi_s = a.phi[rs + kc + i]; }
-        }
-        have_lo = (k & 1) != 0;
-        if (have_lo) {                                            // k odd: k - 1 >= 0 is an anchor level
-            const T sg_lo = a.sig[k - 1];
-            lo_ex_c = exner(sp_c * sg_lo + ptop, tab);
-            lo_ex_s = exner(sp_s * sg_lo + ptop, tab);
-            lo_st_s = a.st[rs + kc - W + i];
-            lo_phi_c = a.phi[rc + kc - W + i];
-            lo_phi_s = a.phi[rs + kc - W + i];
-            phi_c = phi_up(lo_phi_c, st_m, st_c, lo_ex_c, ex_c);
-            phi_s = phi_up(lo_phi_s, lo_st_s, st_s, lo_ex_s, ex_s);
-        }
-        const T rho_c = rho_of(sp_c * sg + ptop, st_c, ex_c), rho_s = rho_of(sp_s * sg + ptop, st_s, ex_s);
-        const T phiv = jph_c * ((phi_s - phi_c) * inv_dy);
-        const T pgv = ((sg * sp_c + sg * sp_s) * T(0.5)) * rcp((rho_c + rho_s) * T(0.5)) * ((sp_s - sp_c) * inv_dy);
-        // ---- vertical advection, dynamics.py:49-52 with iph(sd), jph(sd), sd
-        const T inv_ds = a.inv_dsig[k];
-        const T sdi = (sd_c + sd_e) * T(0.5), sdi_p = (sd_cp + sd_ep) * T(0.5);
-        const T sdj = (sd_c + sd_s) * T(0.5), sdj_p = (sd_cp + sd_sp) * T(0.5);
-        const T dus = -((((su_c + su_m) * T(0.5)) * sdi - ((su_p + su_c) * T(0.5)) * sdi_p) * inv_ds);
-        const T dvs = -((((sv_c + sv_m) * T(0.5)) * sdj - ((sv_p + sv_c) * T(0.5)) * sdj_p) * inv_ds);
-        const T dts = -((((st_c + st_m) * T(0.5)) * sd_c - ((st_p + st_c) * T(0.5)) * sd_cp) * inv_ds);
-        const T dqs = -((((sq_c + sq_m) * T(0.5)) * sd_c - ((sq_p + sq_c) * T(0.5)) * sd_cp) * inv_ds);
-        // ---- momentum update, dynamics.py:186-212
-        // predictor: the stage state IS the base state, its values are in the window already
-        const T pu = (same ? su_c : a.u[rc + kc + i]) * iph_pb;
-        const T pv = (same ? sv_c : a.v[rc + kc + i]) * jph_pb;
-        const T pgfu = a.pgfu[rc + kc + i];
-        const T pu_n = pu - (dut + dus + pgfu) * dt;
-        const T pv_n = pv - (dvt + dvs + phiv + pgv) * dt;
-        T u_n = pu_n * inv_pnu;
-        T v_n = pv_n * inv_pnv;
-        if (pole_edge) v_n *= T(0.0);                               // v_n[:, -1, :] *= 0, dynamics.py:222
-        // ---- advec_t for t and q, dynamics.py:174-181,214-219
-        const T st_e = a.st[rc + kc + ie], st_w = a.st[rc + kc + iw];
-        const T st_n = a.st[rn + kc + i];
-        const T sq_e = a.sq[rc + kc + ie], sq_w = a.sq[rc + kc + iw];
-        const T sq_s = a.sq[rs + kc + i], sq_n = a.sq[rn + kc + i];
-        const T adt = (spu_c * ((st_c + st_e) * T(0.5)) - spu_w * ((st_w + st_c) * T(0.5))) * inv_dxj +
-                           (spv_c * ((st_c + st_s) * T(0.5)) - spv_n * ((st_n + st_c) * T(0.5))) * inv_dy;
-        const T adq = (spu_c * ((sq_c + sq_e) * T(0.5)) - spu_w * ((sq_w + sq_c) * T(0.5))) * inv_dxj +
-                           (spv_c * ((sq_c + sq_s) * T(0.5)) - spv_n * ((sq_n + sq_c) * T(0.5))) * inv_dy;
-        const T t_n = ((same ? st_c : a.t[rc + kc + i]) * pb_c - (adt + dts) * dt) * inv_pn;
-        const T q_n = ((same ? sq_c : a.q[rc + kc + i]) * pb_c - (adq + dqs) * dt) * inv_pn;
-        const long o = (long)j * L * W + kc + i;                 // interior rows: no wrap needed
-        a.ou[o] = u_n;
-        a.ov[o] = v_n;
-        a.ot[o] = t_n;
-        a.oq[o] = q_n;
-        // rotate the vertical window downwards
-        su_p = su_c; sv_p = sv_c; st_p = st_c; sq_p = sq_c;
-        su_c = su_m; sv_c = sv_m; st_c = st_m; sq_c = sq_m;
-        sd_cp = sd_c; sd_ep = sd_e; sd_sp = sd_s;
-    }
-}
-
-// ---------------------------------------------------------------- K4, row-group form
-// A workgroup is R compute waves = R consecutive rows x 62 columns (lanes 1..62; lanes 0 and 63
-// carry the halo columns i-1 / i+1 and are not stored) plus ONE loader wave, marching the levels
-// top-down in lockstep.  Everything the march reads from global memory goes through LDS tiles, one
-// per level, [field][row slot][lane]:
-//   * at the top of the iteration of level k every compute wave REQUESTS its own row of level k-3
-//     (su, sv, st, sq, spu, the phi anchor, pgfu, the base state) and the loader wave the two halo
-//     rows (above and below the group); the requests of the previous iteration (level k-2) are
-//     written to their tile at the END of the iteration, one barrier per level.  A request thus has
-//     two levels of arithmetic to arrive, and the only reader of a requested register is that tile
-//     write, so the compiler's in-order vmcnt wait leaves the newest requests in flight;
-//   * the iteration reads the tiles of level k (own row, rows j-1 / j+1) and k-1 (the level below:
-//     vertical fluxes, the south theta of the geopotential anchor); three tiles rotate;
-//   * columns i-1 / i+1 of the own row come from the neighbouring lanes (DPP);
-//   * sigma-dot at (j, i+1) is the east lane's value (DPP); at (j+1, i) it is rebuilt from the tile;
-//   * the fluxes through the upper faces are the lower-face fluxes of the level above, carried.
-// A row of the stage state leaves HBM (R+2)/R times instead of up to three times.
-constexpr int kUpdCols = 62;
-__device__ __forceinline__ float from_west(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
-}
-// slots of one level tile, in units of 64 lanes
-template <int R> struct UpdTile {
-    static constexpr int kMain = 0;                      // su, sv, st, sq, spu: R+2 slots each (0 = row above the group)
-    static constexpr int kPhi = 5 * (R + 2);             // phi anchor: R+1 slots (own rows, then the row below the group)
-    static constexpr int kOwn = kPhi + R + 1;            // pgfu, u, v, t, q of the base state: R slots each
-    static constexpr int kSlots = kOwn + 5 * R;
-};
-// SAME: the stage state is the base state (predictor): no base-state requests
-template <typename T, int R, bool SAME>
-__global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T> a) {
-    using TL = UpdTile<R>;
-    extern __shared__ unsigned char upd_lds_raw[];
-    __shared__ double tab[kExnerTabDoubles];
-    // the level tables go to LDS too: read from global memory inside the march, their waits (vmcnt
-    // counts in order) would also wait for every request still in flight
-    T *lv_sig = (T *)upd_lds_raw, *lv_dsig = lv_sig + a.L, *lv_inv_dsig = lv_dsig + a.L, *lv_sigb = lv_inv_dsig + a.L;
-    T *tile = lv_sigb + a.L + 1;                     // one word of slack on either side: lane -1 / 64 reads
-    for (int n = threadIdx.x; n < kExnerTabDoubles; n += 64 * (R + 1)) tab[n] = a.exner_tab[n];
-    for (int n = threadIdx.x; n < a.L; n += 64 * (R + 1)) {
-        lv_sig[n] = a.sig[n]; lv_dsig[n] = a.dsig[n]; lv_inv_dsig[n] = a.inv_dsig[n]; lv_sigb[n] = a.sigb[n];
-    }
-    __syncthreads();
-    const Idx ix{a.W, a.H, a.L, a.wrap};
-    const int W = a.W, L = a.L;
-    const int ncol = (W + kUpdCols - 1) / kUpdCols;
-    // Workgroup = ((row group, level segment), column tile); groups come from [j0, j1) then [jb0, jb1).
-    // Each XCD (workgroups b, b+8, ... share one) takes a contiguous run of (group, segment) pairs and
-    // walks it with the GROUP index fastest: the workgroups resident on an XCD at one time are
-    // vertically adjacent groups of a few column tiles, marching in step, so the halo row one of them
-    // requests is the own row its neighbour requests at about the same time -- it comes from that
-    // XCD's L2 instead of HBM.
-    const int nseg = a.nseg;
-    const int na = a.j1 - a.j0, nb = a.jb1 - a.jb0;
-    const int ga = (na + R - 1) / R, gb = (nb + R - 1) / R;
-    const int per_xcd = gridDim.x / 8;                           // = rs_per_xcd * ncol (launch)
-    const int rs_per_xcd = per_xcd / ncol;
-    const int l = blockIdx.x / 8;
-    const int ct = l / rs_per_xcd;
-    const int rowseg = (blockIdx.x % 8) * rs_per_xcd + (l - ct * rs_per_xcd);
-    const int grp = rowseg / nseg, seg = rowseg - grp * nseg;
-    if (grp >= ga + gb) return;                                  // padding workgroups (uniform)
-    const int jg = grp < ga ? a.j0 + grp * R : a.jb0 + (grp - ga) * R;
-    const int jend = min(jg + R, grp < ga ? a.j1 : a.jb1);
-    const int nact = jend - jg;
-    const int k_lo = seg_lo(seg, nseg, L), k_hi = seg_lo(seg + 1, nseg, L);
-    if (k_hi <= k_lo) return;                                    // uniform
-    const int r = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    constexpr int kBuf = TL::kSlots * 64;
-    const int iraw = ct * kUpdCols + lane - 1;
-    const int i = wrapi(iraw, W), ie = i + 1 == W ? 0 : i + 1;
-    const int k0 = k_hi - 1;
-    const int kmin = k_lo > 0 ? k_lo - 1 : 0;                    // tiles exist for levels k0 .. kmin
-    constexpr bool same = SAME;
-    T *const t0 = tile + lane;
-    // tile of the level at distance d below k0: buffers rotate 0, 1, 2
-    int bc = 0, bm = 1, bf = 2;                                  // level k, k-1, k-2 (being filled)
-
-    if (r == R) {
-        // ---- loader wave: the halo rows jg-1 (slot 0) and jend (slot nact+1; its phi anchor: slot nact)
-        const long rn = ix.r3(jg - 1), rs = ix.r3(jend);
-        const int ss = nact + 1;
-        T h[2][10];
-        const auto load = [&](T (&d)[10], int k) {
-            const long kl = (long)k * W;
-            d[0] = a.su[rn + kl + i]; d[1] = a.sv[rn + kl + i]; d[2] = a.st[rn + kl + i]; d[3] = a.sq[rn + kl + i];
-            d[4] = a.su[rs + kl + i]; d[5] = a.sv[rs + kl + i]; d[6] = a.st[rs + kl + i]; d[7] = a.sq[rs + kl + i];
-            d[8] = a.spu[rs + kl + i]; d[9] = a.phi[rs + (long)(k & ~1) * W + i];
-        };
-        const auto put = [&](const T (&d)[10], int buf) {
-            T *t = t0 + buf * kBuf;
-#pragma unroll
-            for (int f = 0; f < 4; ++f) t[(TL::kMain + f * (R + 2)) * 64] = d[f];
-#pragma unroll
-            for (int f = 0; f < 5; ++f) t[(TL::kMain + f * (R + 2) + ss) * 64] = d[4 + f];
-            t[(TL::kPhi + nact) * 64] = d[9];
-        };
-        load(h[0], k0);
-        put(h[0], 0);
-        if (k0 - 1 >= kmin) { load(h[1], k0 - 1); put(h[1], 1); }
-        // requests are unconditional (level clamped to kmin): a conditional one would make the compiler
-        // size its in-order vmcnt waits for the path without it, i.e. wait for the newest requests too
-        load(h[0], max(k0 - 2, kmin));
-        __syncthreads();
-        for (int k = k0;;) {
-            load(h[1], max(k - 3, kmin));
-            if (k - 2 >= kmin) put(h[0], bf);
-            if (k == k_lo) break;
-            __syncthreads();
-            { const int t = bc; bc = bm; bm = bf; bf = t; }
-            --k;
-            load(h[0], max(k - 3, kmin));
-            if (k - 2 >= kmin) put(h[1], bf);
-            if (k == k_lo) break;
-            __syncthreads();
-            { const int t = bc; bc = bm; bm = bf; bf = t; }
-            --k;
-        }
-        return;
-    }
-    if (r >= nact) {                                             // rows past the range: keep the barriers
-        for (int k = k0; k >= k_lo; --k) __syncthreads();
-        return;
-    }
-    const int j = jg + r;
-    const bool store = lane >= 1 && lane <= kUpdCols && iraw < W;
-    const int jg_row = wrapi(a.row0 + j, a.Hg);
-    const T inv_dxj = a.inv_dxj[jg_row], inv_dxh = a.inv_dxh[jg_row], inv_dy = a.inv_dy, dt = a.dt;
-    const T inv_dxj_s = a.inv_dxj[wrapi(a.row0 + j + 1, a.Hg)];
-    const T q_dxj = T(0.25) * inv_dxj, q_dxh = T(0.25) * inv_dxh, q_dy = T(0.25) * inv_dy;
-    const T h_dxj = T(0.5) * inv_dxj, h_dy = T(0.5) * inv_dy;
-    const long rc = ix.r3(j);
-    const T *spr = a.sp;
-    const long p_n = ix.r2(j - 1), p_c = ix.r2(j), p_s = ix.r2(j + 1), p_ss = ix.r2(j + 2);
-    const T sp_c = spr[p_c + i], sp_e = spr[p_c + ie];
-    const T sp_s = spr[p_s + i], sp_se = spr[p_s + ie], sp_ss = spr[p_ss + i];
-    const T sp_n = spr[p_n + i], sp_ne = spr[p_n + ie];
-    const T jph_c = (sp_c + sp_s) * T(0.5), jph_ce = (sp_e + sp_se) * T(0.5);
-    const T jph_n = (sp_n + sp_c) * T(0.5), jph_ne = (sp_ne + sp_e) * T(0.5);
-    const T jph_s = (sp_s + sp_ss) * T(0.5);
-    const T pb_c = a.p[p_c + i], pb_e = a.p[p_c + ie], pb_s = a.p[p_s + i];
-    const T iph_pb = (pb_c + pb_e) * T(0.5), jph_pb = (pb_c + pb_s) * T(0.5);
-    const T pn_c = a.pn[p_c + i], pn_e = a.pn[p_c + ie], pn_s = a.pn[p_s + i];
-    const T inv_pnu = rcp((pn_c + pn_e) * T(0.5)), inv_pnv = rcp((pn_c + pn_s) * T(0.5)), inv_pn = rcp(pn_c);
-    const bool pole_edge = jg_row == a.Hg - 1;
-    const bool coriolis = a.cor_u != nullptr;
-    const T cp_u = coriolis ? a.cor_u[jg_row] : T(0.0), cp_v = coriolis ? a.cor_v[jg_row] : T(0.0);
-    if (seg == 0 && store) a.op[(long)j * W + i] = pn_c;
-    const T pit_c = a.pit[p_c + i], pit_s = a.pit[p_s + i];
-    const T ptop = a.ptop;
-
-    // own-row requests of one level: su, sv, st, sq, spu, phi anchor, pgfu, base u, v, t, q
-    T q[2][11];
-    // (the level's offset is wave-uniform: the request is scalar base + ONE 32-bit byte offset per lane,
-    // the addressing mode that needs no vector arithmetic)
-    const unsigned ob = (unsigned)i * (unsigned)sizeof(T);
-    // (the base goes through an opaque scalar register pair: left visible, the compiler reassociates
-    // it into eleven loop-invariant per-lane 64-bit addresses plus a scalar level offset -- 22 VGPRs
-    // and a 64-bit vector add per request)
-    const auto sbase = [](const T *p) {
-        unsigned long long v = (unsigned long long)p;
-        unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-        asm volatile("" : "+s"(lo), "+s"(hi));
-        return (__attribute__((address_space(1))) char *)(((unsigned long long)hi << 32) | lo);      // global, not flat
-    };
-    const auto load = [&](T (&d)[11], int k) {
-        // (the lane offset is made opaque once per level, so that its zero extension stays next to the
-        // requests and they take the scalar-base + 32-bit-offset form)
-        unsigned ol = ob;
-        asm volatile("" : "+v"(ol));
-        const auto at = [ol, sbase](const T *base) { return *(const __attribute__((address_space(1))) T *)(sbase(base) + ol); };
-        const long o = rc + (long)k * W;
-        d[0] = at(a.su + o); d[1] = at(a.sv + o); d[2] = at(a.st + o); d[3] = at(a.sq + o);
-        d[4] = at(a.spu + o); d[6] = at(a.pgfu + o);
-        d[5] = at(a.phi + (rc + (long)(k & ~1) * W));        // the anchor at or below k (odd k: unused, and a cache hit)
-        if (!same) { d[7] = at(a.u + o); d[8] = at(a.v + o); d[9] = at(a.t + o); d[10] = at(a.q + o); }
-    };
-    const auto put = [&](const T (&d)[11], int buf) {
-        T *t = t0 + buf * kBuf;
-#pragma unroll
-        for (int f = 0; f < 5; ++f) t[(TL::kMain + f * (R + 2) + 1 + r) * 64] = d[f];
-        t[(TL::kPhi + r) * 64] = d[5];
-        t[(TL::kOwn + r) * 64] = d[6];
-        if (!same) {
-#pragma unroll
-            for (int f = 1; f < 5; ++f) t[(TL::kOwn + f * R + r) * 64] = d[6 + f];
-        }
-    };
-    // running sums of conv from the top; fluxes kmh(q) sd through the upper face of level k0
-    // (advec_sig, dynamics.py:49-52): zero at the top of the column (sd wraps to sd[0] = 0), else
-    // rebuilt from level k_hi exactly as the iteration of level k_hi forms its lower-face fluxes
-    // (face_flux_v), so a segmented march gives the same bits
-    T rc_c = T(0.0), rc_s = T(0.0);
-    T fu_up = T(0.0), fv_up = T(0.0), ft_up = T(0.0), fq_up = T(0.0);
-    T cs_u = T(0.0), cs_v = T(0.0);                              // sum_k dsig[k] u_n[k], v_n[k] (pe_pit2d_kernel)
-    load(q[0], k0);
-    if (k_hi < L) {
-        const T *part = a.part + (long)seg * a.part_stride;
-        const T sgb_hi = lv_sigb[k_hi];
-        rc_c = part[p_c + i]; rc_s = part[p_s + i];
-        const T sd_cp = sd_of(rc_c, pit_c, sgb_hi), sd_sp = sd_of(rc_s, pit_s, sgb_hi);
-        const T sd_ep = from_east(sd_cp);
-        const long kp0 = (long)k_hi * W;
-        fu_up = face_flux_v(a.su[rc + kp0 + i], q[0][0], (sd_cp + sd_ep) * T(0.5));
-        fv_up = face_flux_v(a.sv[rc + kp0 + i], q[0][1], (sd_cp + sd_sp) * T(0.5));
-        ft_up = face_flux_v(a.st[rc + kp0 + i], q[0][2], sd_cp);
-        fq_up = face_flux_v(a.sq[rc + kp0 + i], q[0][3], sd_cp);
-    }
-    put(q[0], 0);
-    if (k0 - 1 >= kmin) { load(q[1], k0 - 1); put(q[1], 1); }
-    load(q[0], max(k0 - 2, kmin));                               // unconditional, clamped: see the loader wave
-    // geopotential anchors (see phi_up): an odd level k steps up from the anchor phi[k-1] (tile of
-    // level k-1) and leaves the level k-1 exner factors, anchors and south theta to the even level below
-    bool have_lo = false;
-    T lo_ex_c = T(0.0), lo_ex_s = T(0.0), lo_phi_c = T(0.0), lo_phi_s = T(0.0), lo_st_s = T(0.0);
-    __syncthreads();
-    const auto level = [&](const int k) __attribute__((always_inline)) {
-        const long kc = (long)k * W;
-        const T *tc = t0 + bc * kBuf, *tm = t0 + bm * kBuf;
-        const auto own = [&](const T *t, int f) { return t[(TL::kMain + f * (R + 2) + 1 + r) * 64]; };
-        const auto nrow = [&](const T *t, int f) { return t + (TL::kMain + f * (R + 2) + r) * 64; };
-        const auto srow = [&](const T *t, int f) { return t + (TL::kMain + f * (R + 2) + 2 + r) * 64; };
-        const auto orow = [&](const T *t, int f) { return t + (TL::kMain + f * (R + 2) + 1 + r) * 64; };
-        const T su_c = own(tc, 0), sv_c = own(tc, 1), st_c = own(tc, 2), sq_c = own(tc, 3), spu_c = own(tc, 4);
-        // ---- neighbours: columns i-1 / i+1 of the own row and rows j-1 / j+1 from the tile (the edge
-        //      lanes read a word of the neighbouring slot: they feed nothing that is stored)
-        const T su_w = orow(tc, 0)[-1], su_e = orow(tc, 0)[1];
-        const T sv_w = orow(tc, 1)[-1], sv_e = orow(tc, 1)[1];
-        const T spu_w = orow(tc, 4)[-1], spu_e = orow(tc, 4)[1];
-        const T st_w = orow(tc, 2)[-1], st_e = orow(tc, 2)[1];
-        const T sq_w = orow(tc, 3)[-1], sq_e = orow(tc, 3)[1];
-        const T su_n = *nrow(tc, 0), sv_n = *nrow(tc, 1), sv_ne = nrow(tc, 1)[1], st_n = *nrow(tc, 2), sq_n = *nrow(tc, 3);
-        const T su_s = *srow(tc, 0), sv_s = *srow(tc, 1), st_sl = *srow(tc, 2), sq_s = *srow(tc, 3);
-        const T spu_s = *srow(tc, 4), spu_sw = srow(tc, 4)[-1];
-        const T spv_c = sv_c * jph_c, spv_e = sv_e * jph_ce;
-        const T spv_n = sv_n * jph_n, spv_ne = sv_ne * jph_ne;
-        const T spv_s = sv_s * jph_s;
-        // ---- aflux, dynamics.py:35-46, at (j,i) and (j+1,i); (j,i+1) is the east lane's
-        const T dsg = lv_dsig[k], sgb = lv_sigb[k];
-        T sd_c = T(0.0), sd_s = T(0.0);                           // sd[0] = 0, dynamics.py:44
-        if (k > 0) {
-            rc_c = conv_acc(rc_c, spu_c, spu_w, inv_dxj, sv_c, jph_c, sv_n, jph_n, inv_dy, dsg);
-            rc_s = conv_acc(rc_s, spu_s, spu_sw, inv_dxj_s, sv_s, jph_s, sv_c, jph_c, inv_dy, dsg);
-            sd_c = sd_of(rc_c, pit_c, sgb);
-            sd_s = sd_of(rc_s, pit_s, sgb);
-        }
-        const T sd_e = from_east(sd_c);
-        // ---- advec_m_pu, dynamics.py:55-108
-        // ---- advec_m_pu, dynamics.py:55-108.  Every product there is a product of two averages,
-        //      ((a + b)/2) ((c + d)/2): the quarters are taken out of the sums and folded into the grid
-        //      factors (q_dx = 1/(4 dx)) -- scaling by a power of two commutes with every rounding
-        const T puum = (su_c + su_w) * (spu_c + spu_w);
-        const T puup = (su_e + su_c) * (spu_e + spu_c);
-        const T puvp = (spv_c + spv_e) * (su_c + su_s);
-        const T puvm = (spv_n + spv_ne) * (su_n + su_c);
-        const T pvvm = (sv_c + sv_n) * (spv_c + spv_n);
-        const T pvvp = (sv_s + sv_c) * (spv_s + spv_c);
-        const T pvup = (sv_c + sv_e) * (spu_c + spu_s);
-        const T pvum = (sv_w + sv_c) * (spu_w + spu_sw);
-        T cor_u = T(0.0), cor_v = T(0.0);                         // the reference adds a literal 0
-        if (coriolis) {                                          // dynamics.py:83-92
-            const T pu_at_pv = (((spu_c + spu_s) * T(0.5)) + ((spu_w + spu_sw) * T(0.5))) * T(0.5);    // imh(jph(pu))
-            const T pv_at_pu = (((spv_c + spv_n) * T(0.5)) + ((spv_e + spv_ne) * T(0.5))) * T(0.5);    // iph(jmh(pv))
-            cor_u = cp_u * -pv_at_pu;
-            cor_v = cp_v * pu_at_pv;
-        }
-        const T dut = (puum - puup) * q_dxj + (puvm - puvp) * q_dy + cor_u;
-        const T dvt = (pvvm - pvvp) * q_dy + (pvum - pvup) * q_dxh + cor_v;
-        // ---- advec_t for t and q, dynamics.py:174-181 (flux times ONE average: halves folded, h_dx = 1/(2 dx))
-        const T adt = (spu_c * (st_c + st_e) - spu_w * (st_w + st_c)) * h_dxj +
-                      (spv_c * (st_c + st_sl) - spv_n * (st_n + st_c)) * h_dy;
-        const T adq = (spu_c * (sq_c + sq_e) - spu_w * (sq_w + sq_c)) * h_dxj +
-                      (spv_c * (sq_c + sq_s) - spv_n * (sq_n + sq_c)) * h_dy;
-        // ---- the level below (k-1), from its tile: vertical fluxes and the anchor step.  At k == 0 the
-        //      lower face carries sd[0] = 0: any finite value serves
-        T su_m = su_c, sv_m = sv_c, st_m = st_c, sq_m = sq_c;
-        if (k > 0) { su_m = own(tm, 0); sv_m = own(tm, 1); st_m = own(tm, 2); sq_m = own(tm, 3); }
-        // ---- pgf v-part, dynamics.py:160,167-169: rho and phi of (j,i) and (j+1,i) rebuilt (rho_of / phi_up)
-        const T sg = lv_sig[k];
-        T ex_c, ex_s, phi_c, phi_s, st_s;
-        if (have_lo) {
-            ex_c = lo_ex_c; ex_s = lo_ex_s; phi_c = lo_phi_c; phi_s = lo_phi_s; st_s = lo_st_s;
-        } else {
-            ex_c = exner(sp_c * sg + ptop, tab);
-            ex_s = exner(sp_s * sg + ptop, tab);
-            st_s = st_sl;
-            phi_c = tc[(TL::kPhi + r) * 64]; phi_s = tc[(TL::kPhi + r + 1) * 64];   // an even level's own anchor (unused when k is odd)
-        }
-        have_lo = (k & 1) != 0;
-        if (have_lo) {                                            // k odd: level k-1 >= 0 is the anchor
-            const T sg_lo = lv_sig[k - 1];
-            lo_ex_c = exner(sp_c * sg_lo + ptop, tab);
-            lo_ex_s = exner(sp_s * sg_lo + ptop, tab);
-            lo_st_s = *srow(tm, 2); lo_phi_c = tm[(TL::kPhi + r) * 64]; lo_phi_s = tm[(TL::kPhi + r + 1) * 64];
-            phi_c = phi_up(lo_phi_c, st_m, st_c, lo_ex_c, ex_c);
-            phi_s = phi_up(lo_phi_s, lo_st_s, st_s, lo_ex_s, ex_s);
-        }
-        const T rho_c = rho_of(sp_c * sg + ptop, st_c, ex_c), rho_s = rho_of(sp_s * sg + ptop, st_s, ex_s);
-        const T phiv = jph_c * ((phi_s - phi_c) * inv_dy);
-        // jph(sig p) / jph(rho): the two halves cancel exactly
-        const T pgv = (sg * sp_c + sg * sp_s) * rcp(rho_c + rho_s) * ((sp_s - sp_c) * inv_dy);
-        // ---- vertical advection, dynamics.py:49-52 with iph(sd), jph(sd), sd
-        const T inv_ds = lv_inv_dsig[k];
-        const T fu = face_flux_v(su_c, su_m, (sd_c + sd_e) * T(0.5)), fv = face_flux_v(sv_c, sv_m, (sd_c + sd_s) * T(0.5));
-        const T ft = face_flux_v(st_c, st_m, sd_c), fq = face_flux_v(sq_c, sq_m, sd_c);
-        const T dus = -((fu - fu_up) * inv_ds);
-        const T dvs = -((fv - fv_up) * inv_ds);
-        const T dts = -((ft - ft_up) * inv_ds);
-        const T dqs = -((fq - fq_up) * inv_ds);
-        fu_up = fu; fv_up = fv; ft_up = ft; fq_up = fq;
-        // ---- momentum, theta and q update, dynamics.py:186-219 (predictor: the stage state IS the base state)
-        const T pgfu_c = tc[(TL::kOwn + r) * 64];
-        T bu_c = su_c, bv_c = sv_c, bt_c = st_c, bq_c = sq_c;
-        if (!same) {
-            bu_c = tc[(TL::kOwn + R + r) * 64]; bv_c = tc[(TL::kOwn + 2 * R + r) * 64];
-            bt_c = tc[(TL::kOwn + 3 * R + r) * 64]; bq_c = tc[(TL::kOwn + 4 * R + r) * 64];
-        }
-        const T pu = bu_c * iph_pb;
-        const T pv = bv_c * jph_pb;
-        const T pu_n = pu - (dut + dus + pgfu_c) * dt;
-        const T pv_n = pv - (dvt + dvs + phiv + pgv) * dt;
-        T u_n = pu_n * inv_pnu;
-        T v_n = pv_n * inv_pnv;
-        if (pole_edge) v_n *= T(0.0);                               // v_n[:, -1, :] *= 0, dynamics.py:222
-        const T t_n = (bt_c * pb_c - (adt + dts) * dt) * inv_pn;
-        const T q_n = (bq_c * pb_c - (adq + dqs) * dt) * inv_pn;
-        cs_u = cs_acc(cs_u, u_n, dsg);
-        cs_v = cs_acc(cs_v, v_n, dsg);
-        if (store) {
-            const long o = (long)j * L * W + kc;                 // rows to produce are interior: no wrap
-            unsigned ol = ob;
-            asm volatile("" : "+v"(ol));
-            *(__attribute__((address_space(1))) T *)(sbase(a.ou + o) + ol) = u_n;
-            *(__attribute__((address_space(1))) T *)(sbase(a.ov + o) + ol) = v_n;
-            *(__attribute__((address_space(1))) T *)(sbase(a.ot + o) + ol) = t_n;
-            *(__attribute__((address_space(1))) T *)(sbase(a.oq + o) + ol) = q_n;
-        }
-    };
-    // two request sets that swap BY NAME (loop unrolled by two): a register copy of a value still in
-    // flight would make the wave wait for it at once
-    for (int k = k0;;) {
-        load(q[1], max(k - 3, kmin));
-        level(k);
-        if (k - 2 >= kmin) put(q[0], bf);
-        if (k == k_lo) break;
-        __syncthreads();
-        { const int t = bc; bc = bm; bm = bf; bf = t; }
-        --k;
-        load(q[0], max(k - 3, kmin));
-        level(k);
-        if (k - 2 >= kmin) put(q[1], bf);
-        if (k == k_lo) break;
-        __syncthreads();
-        { const int t = bc; bc = bm; bm = bf; bf = t; }
-        --k;
-    }
-    if (store && a.ocs_u) {                                      // whole column marched (nseg == 1)
-        a.ocs_u[(long)j * W + i] = cs_u;
-        a.ocs_v[(long)j * W + i] = cs_v;
-    }
 }
 
 using PeArgs = PeArgsT<double>;   // the diagnostics and the column physics below are fp64 only
@@ -1515,59 +515,6 @@ static bool upload_as(Pe25d *m, T **dst, const double *src, size_t count) {
 
 static size_t rows_alloc(const Pe25d *m) { return (size_t)m->H + 2 * kGhost; }
 
-// the filter kernels are instantiated per widest composite radix (12 / 16 / 25), so that a plan
-// of small radices (1440 = 10.12.12) is not held to the register budget of a 25-point butterfly;
-// 0 = generic ping-pong passes
-template <typename T> using FilterKernel = void (*)(PeArgsT<T>);
-// plans with their own instantiation (only their passes compiled in): the row lengths of the
-// BASELINE configs and the powers of 16
-constexpr unsigned kMask1440 = pass_bit(5, 2) | pass_bit(4, 3);                    // 1440, 720, 360, 120 ...
-constexpr unsigned kMask2880 = pass_bit(5, 3) | pass_bit(4, 3) | pass_bit(4, 4);   // 2880
-constexpr unsigned kMask4096 = pass_bit(4, 4);                                     // 256, 4096
-template <typename T>
-static FilterKernel<T> spu_filter_kernel_for(const SuperPlan &P) {
-    if (!P.ok) return pe_spu_filter_kernel<T, 0>;
-    if (P.mask == kMask1440) return pe_spu_filter_kernel<T, 12, kMask1440>;
-    if (P.mask == kMask2880) return pe_spu_filter_kernel<T, 16, kMask2880>;
-    if (P.mask == kMask4096) return pe_spu_filter_kernel<T, 16, kMask4096>;
-    if (P.maxr <= 12) return pe_spu_filter_kernel<T, 12>;
-    if (P.maxr <= 16) return pe_spu_filter_kernel<T, 16>;
-    return pe_spu_filter_kernel<T, 25>;
-}
-template <typename T> using FilterLoopKernel = void (*)(PeArgsT<T>, int);
-template <typename T>
-static FilterLoopKernel<T> spu_filter_loop_kernel_for(const SuperPlan &P) {
-    if (!P.ok || P.npass > 4) return nullptr;
-    // the plans these masks stand for start with a pass of radix 5.2 / 5.3 / 4.4 (make_super_plan)
-    if (P.mask == kMask1440 && P.r1[0] * P.r2[0] == 10) return pe_spu_filter_loop_kernel<T, 12, kMask1440, 10>;
-    if (P.mask == kMask2880 && P.r1[0] * P.r2[0] == 15) return pe_spu_filter_loop_kernel<T, 16, kMask2880, 15>;
-    if (P.mask == kMask1440) return pe_spu_filter_loop_kernel<T, 12, kMask1440>;
-    if (P.mask == kMask2880) return pe_spu_filter_loop_kernel<T, 16, kMask2880>;
-    if (P.mask == kMask4096) return pe_spu_filter_loop_kernel<T, 16, kMask4096>;
-    if (P.maxr <= 12) return pe_spu_filter_loop_kernel<T, 12>;
-    if (P.maxr <= 16) return pe_spu_filter_loop_kernel<T, 16>;
-    return pe_spu_filter_loop_kernel<T, 25>;
-}
-template <typename T>
-static FilterKernel<T> pgf_filter_kernel_for(const SuperPlan &P) {
-    if (!P.ok) return pe_pgf_filter_kernel<T, 0>;
-    if (P.mask == kMask1440) return pe_pgf_filter_kernel<T, 12, kMask1440>;
-    if (P.mask == kMask2880) return pe_pgf_filter_kernel<T, 16, kMask2880>;
-    if (P.mask == kMask4096) return pe_pgf_filter_kernel<T, 16, kMask4096>;
-    if (P.maxr <= 12) return pe_pgf_filter_kernel<T, 12>;
-    if (P.maxr <= 16) return pe_pgf_filter_kernel<T, 16>;
-    return pe_pgf_filter_kernel<T, 25>;
-}
-template <typename T>
-static FilterKernel<T> pit2d_kernel_for(const SuperPlan &P) {
-    if (!P.ok) return pe_pit2d_kernel<T, 0>;
-    if (P.mask == kMask1440) return pe_pit2d_kernel<T, 12, kMask1440>;
-    if (P.mask == kMask2880) return pe_pit2d_kernel<T, 16, kMask2880>;
-    if (P.mask == kMask4096) return pe_pit2d_kernel<T, 16, kMask4096>;
-    if (P.maxr <= 12) return pe_pit2d_kernel<T, 12>;
-    if (P.maxr <= 16) return pe_pit2d_kernel<T, 16>;
-    return pe_pit2d_kernel<T, 25>;
-}
 template <typename T>
 static size_t upd_lds_bytes(int R, int L) { return sizeof(T) * ((size_t)3 * (11 * R + 11) * 64 + 2 + 4 * (size_t)L); }
 // looping filter kernels: the complex row + iph(sp) of the row + the row's multiplier
@@ -1665,13 +612,13 @@ static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
                             (int)(L * kColThreads * sizeof(T))) != hipSuccess ||
         hipFuncSetAttribute((const void *)pe_radiation_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(double) * (size_t)L * kRadThreads)) != hipSuccess ||
-        hipFuncSetAttribute((const void *)pe_update_rows_kernel<T, 7, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void *)update_rows_kernel_for<T>(7, true), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)upd_lds_bytes<T>(7, L)) != hipSuccess ||
-        hipFuncSetAttribute((const void *)pe_update_rows_kernel<T, 7, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void *)update_rows_kernel_for<T>(7, false), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)upd_lds_bytes<T>(7, L)) != hipSuccess ||
-        hipFuncSetAttribute((const void *)pe_update_rows_kernel<T, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void *)update_rows_kernel_for<T>(3, true), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)upd_lds_bytes<T>(3, L)) != hipSuccess ||
-        hipFuncSetAttribute((const void *)pe_update_rows_kernel<T, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipFuncSetAttribute((const void *)update_rows_kernel_for<T>(3, false), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)upd_lds_bytes<T>(3, L)) != hipSuccess)
         return "dynamic LDS size";
     return nullptr;
@@ -2049,14 +996,11 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
             const dim3 gg((unsigned)(8 * rs_per_xcd * ((W + kUpdCols - 1) / kUpdCols)));
             const size_t lds = upd_lds_bytes<T>(Rg, L);
             const bool same = a.u == a.su;
-            if (Rg == 7 && same) hipLaunchKernelGGL((pe_update_rows_kernel<T, 7, true>), gg, dim3(64 * 8), lds, st, a);
-            else if (Rg == 7) hipLaunchKernelGGL((pe_update_rows_kernel<T, 7, false>), gg, dim3(64 * 8), lds, st, a);
-            else if (same) hipLaunchKernelGGL((pe_update_rows_kernel<T, 3, true>), gg, dim3(64 * 4), lds, st, a);
-            else hipLaunchKernelGGL((pe_update_rows_kernel<T, 3, false>), gg, dim3(64 * 4), lds, st, a);
+            hipLaunchKernelGGL(update_rows_kernel_for<T>(Rg, same), gg, dim3(64 * (Rg + 1)), lds, st, a);
             return;
         }
         const long tiles = (long)((W + kUpdThreads - 1) / kUpdThreads) * rows * a.nseg;
-        hipLaunchKernelGGL(pe_update_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kUpdThreads), 0, st, a);
+        hipLaunchKernelGGL(update_kernel_for<T>(), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kUpdThreads), 0, st, a);
     };
     m->cs_valid[out_set] = p2;                   // (modes 1 + 2 together cover the rows)
     const bool split = mode != 0 && (j1 - j0) > 2 * kGhost;
@@ -2542,3 +1486,4 @@ void pe25d_timing(Pe25d *m, std::vector<hipEvent_t> *ev, size_t *used) {
 }
 
 }  // namespace gcm
+
