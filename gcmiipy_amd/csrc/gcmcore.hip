@@ -64,11 +64,7 @@ struct gcm_handle {
     bool xch_inflight = false;                 // gcm_band_run: an exchange posted, its unpack still to come
     bool band_overlap = false;                 // deep-halo bands: hide the exchange behind interior rows (gcm_set_band_overlap)
     hipEvent_t ev_pack = nullptr, ev_comm = nullptr;
-    // GCM_PE25D band step as a hipGraph, one per parity of the current state set (the step ping-pongs
-    // between two sets): ~40 launches / event calls per step become one graph launch
-    hipGraphExec_t step_graph[2] = {nullptr, nullptr};
-    double step_graph_dt[2] = {0.0, 0.0};
-    bool graph_ok = true;
+    bool join_pending = false;                 // gcm_band_run (GCM_PE25D): work on the second stream not yet joined
 };
 
 #define HIPCHK(h, call)                                                                    \
@@ -133,8 +129,6 @@ int gcm_destroy(gcm_handle *h) {
     for (void *p : h->allocs) (void)hipFree(p);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->region_ev) (void)hipEventDestroy(e);
-    for (int g = 0; g < 2; ++g)
-        if (h->step_graph[g]) (void)hipGraphExecDestroy(h->step_graph[g]);
     if (h->ev_pack) (void)hipEventDestroy(h->ev_pack);
     if (h->ev_comm) (void)hipEventDestroy(h->ev_comm);
     delete h;
@@ -696,19 +690,6 @@ int gcm_set_exchange(gcm_handle *h, const gcm_exchange *x) {
     h->xch_set = true;
     h->primed = false;
     if (const char *e = getenv("GCM_BAND_OVERLAP")) h->band_overlap = e[0] == '1';
-    for (int g = 0; g < 2; ++g) {                           // captured with the previous exchange
-        if (h->step_graph[g]) (void)hipGraphExecDestroy(h->step_graph[g]);
-        h->step_graph[g] = nullptr;
-    }
-    {
-        // off by default: replaying the step as a graph measured 3 % (N = 8 band of the 1440x720x24 grid:
-        // 0.416 vs 0.430 ms; the gaps between the small kernels of a band are GPU-side), and a captured
-        // RCCL exchange between devices cannot be rehearsed on the one-GPU development box
-        // Only with the loopback exchange: capturing RCCL's send/recv group (self-ring, one GPU)
-        // segfaults inside the capture on this ROCm, whichever stream carries it.
-        const char *e = getenv("GCM_BAND_GRAPH");
-        h->graph_ok = e && e[0] == '1' && x->send == nullptr;
-    }
     // GCM_PE25D: the edge rows of a stage are updated and packed into the send buffers on the
     // handle's second stream (gcm_set_halo_buffers)
     if (h->pe) return pe25d_set_halo_buffers(h->pe, x->send_north, x->send_south, h->stream, &h->err);
@@ -767,14 +748,15 @@ static int band_pack_exchange(gcm_handle *h) {
     return band_exchange(h);
 }
 
-// one GCM_PE25D band step: per Euler stage the edge rows + pack on the second stream, the interior
-// rows on the compute stream, then the exchange behind the pack (it overlaps the interior rows)
+// one GCM_PE25D band step: per Euler stage the edge rows + pack on the library's second stream, the interior
+// rows on the compute stream, then the exchange and the unpack behind the pack on that same second stream
+// (they overlap the interior rows).  The compute stream carries K2a -> K3 -> K4 of the band's OWN rows and
+// never reads a ghost row (pe25d_kernels.hip, half_t), so it does not wait for the exchange: everything that
+// reads ghost rows -- the next stage's K1, column sums, edge rows -- is queued on the second stream, behind
+// the unpack, in stream order.  gcm_band_run joins the two streams once, when it returns.
+// GCM_BAND_COMM_STREAM=1: the exchange on the comm stream and a join per stage, as in round 1.
 static int band_step_pe(gcm_handle *h, double dt) {
     int rc = GCM_OK;
-    // The exchange follows the edge rows' pack on the SAME stream (the handle's second one), and so
-    // does the unpack: no cross-queue dependency between pack, send/recv and unpack (each costs
-    // 10-20 us on this chip; trace of the N = 8 band); the compute stream joins once, after the
-    // unpack.  GCM_BAND_COMM_STREAM=1: the exchange on the comm stream, as before.
     static const bool on_comm = getenv("GCM_BAND_COMM_STREAM") && getenv("GCM_BAND_COMM_STREAM")[0] == '1';
     hipStream_t ax = on_comm ? nullptr : pe25d_aux_stream(h->pe);
     for (int stage = 0; stage < 2; ++stage) {
@@ -782,68 +764,14 @@ static int band_step_pe(gcm_handle *h, double dt) {
         if (ax) {
             if ((rc = band_post(h, false, ax))) return rc;
             if ((rc = gcm_halo_unpack2(h, h->xch.recv_north, h->xch.recv_south, ax))) return rc;
-            HIPCHK(h, hipEventRecord(h->ev_comm, ax));
+            h->join_pending = true;
         }
         if ((rc = pe25d_step_phase(h->pe, 2 * stage + 1, dt, h->stream, &h->err))) return rc;
-        if (ax) {
-            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_comm, 0));
-        } else {
+        if (!ax) {
             if ((rc = pe25d_wait_edges(h->pe, h->comm, &h->err))) return rc;
             if ((rc = band_exchange(h))) return rc;
         }
     }
-    return GCM_OK;
-}
-
-// The same step through a hipGraph: captured once per parity of the current state set (and per dt)
-// from the very calls above -- the second and the comm stream join the capture through the events
-// the sequence already uses and are joined back before it ends -- then replayed.  Any failure to
-// capture (e.g. an exchange library that cannot be captured) switches the handle back to plain
-// launches for good; results are identical either way.
-static int band_step_pe_graph(gcm_handle *h, double dt) {
-    const int par = pe25d_parity(h->pe);
-    if (!pe25d_step_is_steady(h->pe)) return band_step_pe(h, dt);       // first step after a new state: not a step to record or replay
-    if (h->step_graph[par] && h->step_graph_dt[par] == dt) {
-        HIPCHK(h, hipGraphLaunch(h->step_graph[par], h->stream));
-        pe25d_advance_step(h->pe);
-        return GCM_OK;
-    }
-    if (h->step_graph[par]) {
-        (void)hipGraphExecDestroy(h->step_graph[par]);
-        h->step_graph[par] = nullptr;
-    }
-    int saved[4];
-    pe25d_host_state(h->pe, true, saved);
-    hipGraph_t g = nullptr;
-    hipGraphExec_t exec = nullptr;
-    const char *why = "";
-    // (the null stream cannot be captured: such a handle keeps plain launches)
-    bool ok = h->stream != nullptr && hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed) == hipSuccess;
-    if (!ok) why = "begin capture";
-    if (ok) {
-        const int rc = band_step_pe(h, dt);                  // recorded, not executed; the host state advances
-        const hipError_t e = hipStreamEndCapture(h->stream, &g);
-        ok = rc == GCM_OK && e == hipSuccess && g != nullptr;
-        if (!ok) why = rc ? h->err.c_str() : hipGetErrorString(e);
-    }
-    if (ok) {
-        ok = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0) == hipSuccess;
-        if (!ok) why = "instantiate";
-    }
-    if (g) (void)hipGraphDestroy(g);
-    {
-        const char *vb = getenv("GCM_VERBOSE");
-        if (vb && vb[0] == '1') fprintf(stderr, "gcmcore: band step graph (parity %d): %s %s\n", par, ok ? "captured" : "not captured, plain launches:", why);
-    }
-    if (!ok) {
-        (void)hipGetLastError();
-        h->graph_ok = false;
-        pe25d_host_state(h->pe, false, saved);
-        return band_step_pe(h, dt);
-    }
-    h->step_graph[par] = exec;
-    h->step_graph_dt[par] = dt;
-    HIPCHK(h, hipGraphLaunch(exec, h->stream));
     return GCM_OK;
 }
 
@@ -868,7 +796,15 @@ int gcm_band_run(gcm_handle *h, int nsteps, double dt) {
             h->primed = true;
         }
         for (int n = 0; n < nsteps; ++n)
-            if ((rc = h->graph_ok ? band_step_pe_graph(h, dt) : band_step_pe(h, dt))) return rc;
+            if ((rc = band_step_pe(h, dt))) return rc;
+        if (h->join_pending) {
+            // the one join of the run: what follows on the compute stream (the caller's gcm_get_state,
+            // diagnostics, the next run) also follows the last unpack on the second stream
+            hipStream_t ax = pe25d_aux_stream(h->pe);
+            HIPCHK(h, hipEventRecord(h->ev_comm, ax));
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_comm, 0));
+            h->join_pending = false;
+        }
         return GCM_OK;
     }
     const int k = h->G / kGhost;                            // steps per exchange

@@ -54,6 +54,7 @@ struct PeArgsT {
     int j0, j1;                            // rows to produce
     int jb0, jb1;                          // second row range of the same launch (K4 edge rows), or empty
     int nseg;                              // K4 marches the column in nseg level segments (1: whole column)
+    int cs_rows, geo_j0, geo_j1;           // pe_geopot_kernel: also form the rows' column sums; rows to form phi for
     long part_stride;                      // elements per slab of `part`
     T dt, inv_dy, ptop;
 };
@@ -148,7 +149,7 @@ __device__ __forceinline__ T cs_acc(T acc, T x, T dsg) { return fma(x, dsg, acc)
 // of small radices (1440 = 10.12.12) is not held to the register budget of a 25-point butterfly;
 // 0 = generic ping-pong passes
 template <typename T> using FilterKernel = void (*)(PeArgsT<T>);
-template <typename T> using FilterLoopKernel = void (*)(PeArgsT<T>, int);
+template <typename T> using FilterLoopKernel = void (*)(PeArgsT<T>, int, int);   // (args, pairs per workgroup, y-block that forms pit or -1)
 // plans with their own instantiation (only their passes compiled in): the row lengths of the
 // BASELINE configs and the powers of 16
 constexpr unsigned kMask1440 = pass_bit(5, 2) | pass_bit(4, 3);                    // 1440, 720, 360, 120 ...

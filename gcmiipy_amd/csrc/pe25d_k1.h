@@ -2,6 +2,7 @@
 // chooses the instantiation for a plan.  Included by pe25d_k1_f64.hip / pe25d_k1_f32.hip only.
 #pragma once
 #include "pe25d_dev.h"
+#include "pe25d_pit2d.h"
 
 namespace gcm {
 
@@ -51,10 +52,16 @@ __global__ __launch_bounds__(512) void pe_spu_filter_kernel(PeArgsT<T> a) {
 // left inside the loop are LDS round trips and barriers.
 // NIN: radix of the plan's first pass (inputs per thread) where the instantiation knows it, else MAXR
 template <typename T, int MAXR, unsigned MASK = 0, int NIN = MAXR>
-__global__ __launch_bounds__(512) void pe_spu_filter_loop_kernel(PeArgsT<T> a, int pairs_per_wg) {
+__global__ __launch_bounds__(512) void pe_spu_filter_loop_kernel(PeArgsT<T> a, int pairs_per_wg, int pit_block) {
     using V = typename Vec2<T>::type;
     extern __shared__ unsigned char lds_raw[];
     V *x = (V *)lds_raw;
+    if ((int)blockIdx.y == pit_block) {
+        // one more workgroup per row: pit and p_n from the 2-D column sums (pe_pit2d_row) -- independent
+        // of the pairs' transforms, and a launch less on the stage's dependency chain
+        pe_pit2d_row<T, MAXR, MASK>(a, x, blockIdx.x);
+        return;
+    }
     const Idx ix{a.W, a.H, a.L, a.wrap};
     const int W = a.W, L = a.L;
     const int j = a.j0 + blockIdx.x;

@@ -28,6 +28,22 @@ namespace gcm {
 // The per-level stp that phi needs after the column sum is parked in LDS, park[k][thread],
 // instead of a round trip through HBM.
 constexpr int kColThreads = 128;
+template <typename T>
+__device__ __forceinline__ T column_sum(const T *col, const T *dsig, int L, int W) {
+    // eight levels requested at a time, then added in order (a load per iteration waits a memory
+    // latency per level: 20 us for the two ghost rows of a band, on the stage's critical path)
+    T acc = T(0.0);
+    int k = L - 1;
+    for (; k >= 7; k -= 8) {
+        T x[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) x[n] = col[(long)(k - n) * W];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc = cs_acc(acc, x[n], dsig[k - n]);
+    }
+    for (; k >= 0; --k) acc = cs_acc(acc, col[(long)k * W], dsig[k]);
+    return acc;
+}
 // LMAX > 0: L <= LMAX and the per-level stp stay in registers (loops unrolled over LMAX; no LDS
 // park, so the occupancy is not limited by it); LMAX == 0: any L, stp parked in LDS
 template <typename T, int LMAX = 0>
@@ -45,10 +61,17 @@ __global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
     const int per_xcd = gridDim.x / 8;
     const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     const int jrel = tile / iblocks;
-    if (jrel >= a.j1 - a.j0) return;
+    const int na = a.j1 - a.j0;
+    if (jrel >= na + (a.jb1 - a.jb0)) return;
     const int i = (tile - jrel * iblocks) * kColThreads + threadIdx.x;
-    const int j = a.j0 + jrel;
+    const int j = jrel < na ? a.j0 + jrel : a.jb0 + (jrel - na);
     if (i >= W) return;
+    if (a.cs_rows) {
+        // a band's ghost rows in one launch: their column sums too (see pe_colsum_kernel)
+        a.scs_u[ix.r2(j) + i] = column_sum(a.su + ix.r3(j) + i, a.dsig, L, W);
+        a.scs_v[ix.r2(j) + i] = column_sum(a.sv + ix.r3(j) + i, a.dsig, L, W);
+    }
+    if (j < a.geo_j0 || j >= a.geo_j1) return;
     T *pk = park + threadIdx.x;
     const int jg = wrapi(a.row0 + j, a.Hg);
     const T spc = a.sp[ix.r2(j) + i];
@@ -193,22 +216,6 @@ __global__ __launch_bounds__(256) void pe_part_kernel(PeArgsT<T> a) {
     }
 }
 
-template <typename T>
-__device__ __forceinline__ T column_sum(const T *col, const T *dsig, int L, int W) {
-    // eight levels requested at a time, then added in order (a load per iteration waits a memory
-    // latency per level: 20 us for the two ghost rows of a band, on the stage's critical path)
-    T acc = T(0.0);
-    int k = L - 1;
-    for (; k >= 7; k -= 8) {
-        T x[8];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) x[n] = col[(long)(k - n) * W];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) acc = cs_acc(acc, x[n], dsig[k - n]);
-    }
-    for (; k >= 0; --k) acc = cs_acc(acc, col[(long)k * W], dsig[k]);
-    return acc;
-}
 // U, V of the stage state's rows [j0, j1) and [jb0, jb1): the rows no K4 has produced them for (a
 // state that came through gcm_set_state; a band's ghost rows, which the exchange fills)
 template <typename T>
@@ -798,7 +805,10 @@ void pe25d_destroy(Pe25d *m) {
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->ev_a) (void)hipEventDestroy(m->ev_a);
     if (m->ev_edges) (void)hipEventDestroy(m->ev_edges);
-    if (m->aux) (void)hipStreamDestroy(m->aux);
+    if (m->aux) {
+        (void)hipStreamSynchronize(m->aux);      // (a band's last exchange may still be unpacking)
+        (void)hipStreamDestroy(m->aux);
+    }
     for (void *p : m->allocs) (void)hipFree(p);
     delete m;
 }
@@ -914,45 +924,49 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         a.ocs_u = bufs<T>(m).cs[out_set][0];
         a.ocs_v = bufs<T>(m).cs[out_set][1];
     }
+    // Two chains on two streams (a cross-queue dependency costs ~10 us on this chip when the waiting queue
+    // is already idle, ~3 us when the event completed earlier: tools/micro/sync_cost.hip):
+    //   A, the caller's stream:  K2a (own rows) -> K3 -> K4 (all rows, or the interior rows of a band)
+    //   B, the second stream:    column sums and anchors of the ghost rows -> K1 (+ pit) [-> a band's edge
+    //                            rows: their partial sums, K4, pack; the exchange and the unpack follow]
+    // A is the long chain and runs without waiting for anything that has not long finished: K4 waits for
+    // B's K1 (done while K3 runs), the next stage's K2a for B's edge rows (done while the interior rows
+    // run).  A never touches ghost rows, so it never waits for an exchange; B does, in stream order.
+    hipStream_t sb = m->aux ? m->aux : s;
+    // pe_geopot_kernel over the rows of `c` ([j0, j1) and [jb0, jb1)); c.geo_j0 / geo_j1: the rows it forms phi
+    // for, c.cs_rows: it also forms the column sums of all its rows
+    const auto geopot = [&](const PeArgsT<T> &c, hipStream_t st) {
+        const int rows = (c.j1 - c.j0) + (c.jb1 - c.jb0);
+        if (rows <= 0) return;
+        const long tiles = (long)((W + kColThreads - 1) / kColThreads) * rows;
+        const dim3 gg((unsigned)((tiles + 7) / 8 * 8));
+        if (L <= 24) hipLaunchKernelGGL((pe_geopot_kernel<T, 24>), gg, dim3(kColThreads), 0, st, c);
+        else if (L <= 40) hipLaunchKernelGGL((pe_geopot_kernel<T, 40>), gg, dim3(kColThreads), 0, st, c);
+        else hipLaunchKernelGGL((pe_geopot_kernel<T, 0>), gg, dim3(kColThreads), sizeof(T) * (size_t)L * kColThreads, st, c);
+    };
     if (mode != 2) {
-        // two independent chains: K1 -> K2b (mass flux, pit) on the caller's stream, K2a -> K3
-        // (geopotential, filtered pressure-gradient force) on the handle's second stream.  The FFT
-        // kernels are latency bound and the column kernels bandwidth bound, so they share the chip.
-        // (Which chain sits on which stream makes no difference: they take about equally long.)
-        hipStream_t s2 = m->aux ? m->aux : s;
+        a.j0 = j0;
+        a.j1 = j1 + ext;
+        // ---- chain B: everything that reads the whole stage state, ghost rows included
         if (m->aux) {
             (void)hipEventRecord(m->ev_fork, s);
             (void)hipStreamWaitEvent(m->aux, m->ev_fork, 0);
         }
-        a.j0 = j0;
-        a.j1 = j1 + ext;
         {
-            const long tiles = (long)((W + kColThreads - 1) / kColThreads) * (a.j1 - a.j0);
-            const dim3 gg((unsigned)((tiles + 7) / 8 * 8));
-            if (L <= 24) hipLaunchKernelGGL((pe_geopot_kernel<T, 24>), gg, dim3(kColThreads), 0, s2, a);
-            else if (L <= 40) hipLaunchKernelGGL((pe_geopot_kernel<T, 40>), gg, dim3(kColThreads), 0, s2, a);
-            else hipLaunchKernelGGL((pe_geopot_kernel<T, 0>), gg, dim3(kColThreads), sizeof(T) * (size_t)L * kColThreads, s2, a);
-        }
-        static const bool no_loop = getenv("GCM_PE_FILTER_NO_LOOP") != nullptr;        // diagnostic: one workgroup per pair
-        const FilterLoopKernel<T> k1 = (m->cfg.filter && W > 1 && !no_loop) ? spu_filter_loop_kernel_for<T>(m->cplan) : nullptr;
-        if (k1) {
-            // all pairs of a row in one workgroup when there are rows enough to fill the chip, else groups
-            const int rows = a.j1 - a.j0;
-            const int groups = std::min(pairs, std::max(1, (3 * m->cus + rows - 1) / rows));
-            const int ppw = (pairs + groups - 1) / groups;
-            hipLaunchKernelGGL(k1, dim3(rows, (pairs + ppw - 1) / ppw), dim3(fft_threads), filter_loop_lds_bytes<T>(m), s, a, ppw);
-        } else {
-            hipLaunchKernelGGL(spu_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, s, a);
-        }
-        if (p2) {
-            // rows whose sums no K4 left: all of a freshly set state, else a band's two ghost rows
-            // next to its own (pit of row j takes V of row j - 1; the intermediates extend to row j1)
+            // rows whose column sums no K4 left: all of a freshly set state, else a band's two ghost rows
+            // next to its own (pit of row j takes V of row j - 1; the intermediates extend to row j1) --
+            // and, in the same launch, the geopotential of a band's south ghost row (K4 of row j1 - 1 takes
+            // phi of row j1)
             PeArgsT<T> c = a;
-            if (!m->cs_valid[stage_set]) {
+            c.jb0 = c.jb1 = 0;
+            bool fresh = false;
+            if (!p2) {
+                c.j0 = j1; c.j1 = j1 + ext;
+            } else if (!m->cs_valid[stage_set]) {
                 c.j0 = m->wrap ? 0 : -1;
                 c.j1 = m->H + ext;
-                c.jb0 = c.jb1 = 0;
                 m->cs_valid[stage_set] = true;
+                fresh = true;
             } else if (m->nseg_edge > 1) {                   // + the own edge rows (marched in segments: no sums from K4)
                 c.j0 = -1; c.j1 = kGhost;
                 c.jb0 = m->H - kGhost; c.jb1 = m->H + 1;
@@ -960,25 +974,65 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
                 c.j0 = -1; c.j1 = 0;
                 c.jb0 = m->H; c.jb1 = m->H + 1;
             }
-            if (!m->wrap || c.j1 - c.j0 > 1) {
-                const int rows = (c.j1 - c.j0) + (c.jb1 - c.jb0);
-                hipLaunchKernelGGL(pe_colsum_kernel<T>, dim3((unsigned)((W + 255) / 256) * rows), dim3(256), 0, s, c);
+            c.cs_rows = p2 ? 1 : 0;
+            c.geo_j0 = j1; c.geo_j1 = j1 + ext;
+            if (fresh && (c.j1 - c.j0) > 8) {
+                // a whole state's sums: the plain column-sum kernel (no thermodynamics compiled in), then the ghost row
+                hipLaunchKernelGGL(pe_colsum_kernel<T>, dim3((unsigned)((W + 255) / 256) * (c.j1 - c.j0)), dim3(256), 0, sb, c);
+                c.cs_rows = 0;
+                c.j0 = j1; c.j1 = j1 + ext;
             }
-            hipLaunchKernelGGL(pit2d_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0), dim3(fft_threads), lds + sizeof(T) * (size_t)W, s, a);
-        } else {
-            const long tiles = (long)((W + 255) / 256) * (a.j1 - a.j0);
-            hipLaunchKernelGGL(pe_pit_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, s, a);
+            if (!m->wrap || (fresh && c.cs_rows)) geopot(c, sb);
         }
-        if (mode == 1 && async_edges(m) && m->aux) (void)hipEventRecord(m->ev_a, s);
+        static const bool no_loop = getenv("GCM_PE_FILTER_NO_LOOP") != nullptr;        // diagnostic: one workgroup per pair
+        const FilterLoopKernel<T> k1 = (m->cfg.filter && W > 1 && !no_loop) ? spu_filter_loop_kernel_for<T>(m->cplan) : nullptr;
+        bool pit_done = false;
+        if (k1) {
+            // all pairs of a row in one workgroup when there are rows enough to fill the chip, else groups;
+            // with the 2-D form of pit one more workgroup per row forms pit and p_n (pe_pit2d_row)
+            const int rows = a.j1 - a.j0;
+            const int groups = std::min(pairs, std::max(1, (3 * m->cus + rows - 1) / rows));
+            const int ppw = (pairs + groups - 1) / groups;
+            const int ny = (pairs + ppw - 1) / ppw;
+            hipLaunchKernelGGL(k1, dim3(rows, ny + (p2 ? 1 : 0)), dim3(fft_threads), filter_loop_lds_bytes<T>(m), sb, a, ppw, p2 ? ny : -1);
+            pit_done = p2;
+        } else {
+            hipLaunchKernelGGL(spu_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, sb, a);
+        }
+        if (p2 && !pit_done) {
+            hipLaunchKernelGGL(pit2d_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0), dim3(fft_threads), lds + sizeof(T) * (size_t)W, sb, a);
+        } else if (!p2) {
+            const long tiles = (long)((W + 255) / 256) * (a.j1 - a.j0);
+            hipLaunchKernelGGL(pe_pit_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, sb, a);
+        }
+        if (m->aux) (void)hipEventRecord(m->ev_a, m->aux);      // (what K4 of the interior rows takes from this chain)
+        if (mode == 1 && (j1 - j0) > 2 * kGhost && p2 && m->nseg_edge > 1) {
+            // a band's edge rows are marched in level segments (see mode 1 below): the partial sums of conv
+            // they start from, behind K1 (beside the interior rows' K4 this kernel took 50 us instead of 14)
+            PeArgsT<T> c = a;
+            c.nseg = m->nseg_edge;
+            c.j0 = j0; c.j1 = j0 + kGhost + 1;            // (K4 of row j also takes the sums of row j + 1)
+            c.jb0 = j1 - kGhost; c.jb1 = j1 + 1;
+            hipLaunchKernelGGL(pe_part_kernel<T>, dim3((unsigned)((W + 255) / 256) * (2 * kGhost + 2)), dim3(256), 0, sb, c);
+        }
+        // ---- chain A: geopotential of the own rows, then the filtered pressure-gradient force
+        a.j0 = j0;
         a.j1 = j1;
+        {
+            PeArgsT<T> c = a;
+            c.jb0 = c.jb1 = 0;
+            c.cs_rows = 0;
+            c.geo_j0 = j0; c.geo_j1 = j1;
+            geopot(c, s);
+        }
         // (a looping form of this filter, as K1's, was built and is 25 % SLOWER: its requests and the
         // per-column thermodynamics push it to 187 VGPRs, two waves per SIMD instead of four)
         // (launched with whole waves -- 192 threads for the 144 butterflies of a 1440 row, so that the
         // per-column thermodynamics ahead of the transform fills its lanes -- it takes the same time)
-        hipLaunchKernelGGL(pgf_filter_kernel_for<T>(m->cplan), dim3((unsigned)(8 * ((a.j1 - a.j0 + 7) / 8) * pairs)), dim3(fft_threads), lds, s2, a);
+        hipLaunchKernelGGL(pgf_filter_kernel_for<T>(m->cplan), dim3((unsigned)(8 * ((a.j1 - a.j0 + 7) / 8) * pairs)), dim3(fft_threads), lds, s, a);
         if (m->aux) {
-            (void)hipEventRecord(m->ev_join, m->aux);
-            (void)hipStreamWaitEvent(s, m->ev_join, 0);
+            if (mode == 1 && async_edges(m)) (void)hipEventRecord(m->ev_join, s);      // the edge rows' K4 on B takes pgfu
+            (void)hipStreamWaitEvent(s, m->ev_a, 0);                                   // K4 on A takes spu, pit (and a band's ghost anchors)
         }
     }
     auto update_rows = [&](int r0, int r1, int rb0, int rb1, hipStream_t st) {   // rows [r0, r1) and [rb0, rb1), one launch
@@ -1010,23 +1064,19 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         tick(m, s);
     } else if (mode == 1) {
         // the rows the neighbours wait for (an unsplittable, tiny band: all of them).  With send
-        // buffers registered they are updated and packed on the second stream, which has the
-        // K2a -> K3 chain already and waits for K1 -> K2b here; the caller's stream goes straight
-        // on to the interior rows (mode 2), so the two launches share the chip.
+        // buffers registered they are updated and packed on the second stream (chain B), which waits
+        // for K3 here; the caller's stream goes straight on to the interior rows (mode 2), so the
+        // two launches share the chip.
         const bool as = async_edges(m);
         hipStream_t se = as && m->aux ? m->aux : s;
-        if (as && m->aux) (void)hipStreamWaitEvent(m->aux, m->ev_a, 0);
+        if (as && m->aux) (void)hipStreamWaitEvent(m->aux, m->ev_join, 0);
         if (split && p2 && m->nseg_edge > 1) {
             // the edge rows in level segments: a quarter of the chain of dependent levels, so the pack
             // and the exchange start while the interior rows are still at work
             PeArgsT<T> keep = a;
             a.nseg = m->nseg_edge;
             a.ocs_u = a.ocs_v = nullptr;
-            // the partial sums of conv they start from (launched behind K1 instead, beside K3, this
-            // kernel takes 14 us instead of 50 -- but on the stage's critical chain, a net loss)
-            a.j0 = j0; a.j1 = j0 + kGhost + 1;            // (K4 of row j also takes the sums of row j + 1)
-            a.jb0 = j1 - kGhost; a.jb1 = j1 + 1;
-            hipLaunchKernelGGL(pe_part_kernel<T>, dim3((unsigned)((W + 255) / 256) * (2 * kGhost + 2)), dim3(256), 0, se, a);
+            // (the partial sums of conv they start from: pe_part_kernel, queued behind K1 above)
             update_rows(j0, j0 + kGhost, j1 - kGhost, j1, se);
             a = keep;
         } else if (split) {
@@ -1175,28 +1225,6 @@ int pe25d_set_halo_buffers(Pe25d *m, void *north, void *south, hipStream_t s, st
     m->send_buf[1] = south;
     m->edges_pending = false;
     return GCM_OK;
-}
-
-// host-side step state (which state set is current, ...): gcm_band_run replays a captured step as a
-// hipGraph, which runs none of the host code that advances this state
-void pe25d_host_state(Pe25d *m, bool save, int st[4]) {
-    if (save) {
-        st[0] = m->cur_i; st[1] = m->star_valid; st[2] = m->pack_set;
-        st[3] = (m->edges_pending ? 1 : 0) | (m->cs_valid[0] ? 2 : 0) | (m->cs_valid[1] ? 4 : 0) | (m->cs_valid[2] ? 8 : 0);
-    } else {
-        m->cur_i = st[0]; m->star_valid = st[1] != 0; m->pack_set = st[2]; m->edges_pending = (st[3] & 1) != 0;
-        for (int n = 0; n < 3; ++n) m->cs_valid[n] = (st[3] & (2 << n)) != 0;
-    }
-}
-// a step recorded now replays correctly later only if it does not contain the one-off column sums
-// of a freshly set state (see half_t)
-bool pe25d_step_is_steady(const Pe25d *m) { return !m->pit2d || m->nseg != 1 || m->upd_rows == 0 || m->cs_valid[m->cur_i]; }
-int pe25d_parity(const Pe25d *m) { return m->cur_i; }
-void pe25d_advance_step(Pe25d *m) {          // what one full band step (phases 0..3) leaves behind
-    m->cur_i = 1 - m->cur_i;
-    m->star_valid = false;
-    m->pack_set = -1;
-    m->edges_pending = false;
 }
 
 int pe25d_wait_edges(Pe25d *m, hipStream_t s, std::string *err) {

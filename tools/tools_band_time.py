@@ -47,7 +47,7 @@ def main():
         from gcmiipy_amd.rccl import RcclP2P
         tdist = RcclP2P(None, 0, 1)
     desc, H, W, L, model, tracer, bpc, dt = bench.WORKLOADS[a.workload]
-    # a stream of its own, as bench.py's bands use (a step captured as a hipGraph cannot live on the null stream)
+    # a stream of its own, as bench.py's bands use
     torch.cuda.set_stream(torch.cuda.Stream())
     geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig) if model == "PE25D" else None
     full = bench.synth(a.workload, H, W, L, geom=geom)
@@ -106,9 +106,23 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / steps
         assert core.diag(_lib.DIAG_ANY_NAN) == 0.0, "state went NaN: timing invalid"
+        # What the HOST needs to queue a step, measured where no call can block on a full queue: the steps
+        # are queued behind one long spin kernel on the compute stream (torch.cuda._sleep, ~40 ms), i.e. into
+        # a device that executes none of them before the host is done.  `host_ms_per_step` above is taken
+        # on a busy device and also counts the time the host is held back by the queue (it tracks the band's
+        # GPU time); this figure does not depend on the band's size.
+        nq = max(k, 4) // k * k
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(40e-3 * 2.0e9))
+        t0 = time.perf_counter()
+        runner.run(nq, dt)
+        host_idle_ms = (time.perf_counter() - t0) * 1e3 / nq
+        torch.cuda.synchronize()
         res.append({"split": n, "band_rows": nrows, "halo_steps": k, "ms_per_step": ms, "host_ms_per_step": host_ms,
+                    "host_queue_ms_per_step_idle_device": host_idle_ms,
                     "one_library_call_per_run": bool(getattr(runner, "native", False))})
-        print("N=%d  band of %4d rows  %.4f ms/step  (host queues a step in %.4f ms)" % (n, nrows, ms, host_ms), flush=True)
+        print("N=%d  band of %4d rows  %.4f ms/step  (host queues a step in %.4f ms behind a busy queue, %.4f ms into an idle one)"
+              % (n, nrows, ms, host_ms, host_idle_ms), flush=True)
         core.close()
     base = res[0]["ms_per_step"] if res and res[0]["split"] == 1 else None
     for r in res:
