@@ -20,9 +20,12 @@ namespace gcm {
 
 constexpr int kMaxSeg = 4;      // level segments of the update kernel (short bands)
 constexpr int kMaxEdgeCols = 96; // K3: columns that are multiples of 64 (W <= 5120 + rounding)
-// real-type specific pieces: reciprocal and (p/P0)**kappa (fp32: v_rcp_f32 is 1 ulp; powf)
+// real-type specific pieces: reciprocal and (p/P0)**kappa.  fp32: v_rcp_f32 is 1 ulp; the Exner function goes
+// through the float64 table + series of gcm_math.h and is rounded to float once.  (__powf, which this used
+// to be, expands to ~110 VALU instructions -- the fp32 update kernel executed TWICE the vector instructions
+// of the fp64 one, profiles/r03 -- and is less accurate than one rounding of the float64 value.)
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float exner(float p, const double *) { return __powf(p * 1e-5f, (float)kKappa); }
+__device__ __forceinline__ float exner(float p, const double *tab) { return (float)exner((double)p, tab); }
 
 template <typename T>
 struct PeArgsT {
