@@ -20,6 +20,7 @@ F64, F32 = 0, 1
 ADV_UPWIND, ADV_FV_UPWIND, ADV_FV_PLAIN, ADV_VANLEER, ADV_MOMENTUM = range(5)
 DIAG_ANY_NAN, DIAG_MAX_U, DIAG_MEAN_P, DIAG_SUM_P, DIAG_MIN_U, DIAG_MAX_V, DIAG_MIN_V = range(7)
 DIAG_TV_P, DIAG_TV_U, DIAG_TV_V, DIAG_TV_T, DIAG_TV_Q = range(7, 12)
+INT_SPU, INT_PIT, INT_PN, INT_PHI, INT_PGFU = range(5)
 FL_VAN_LEER, FL_CALC_R, FL_DONOR_FLUX, FL_DONOR_ADVECTION = range(4)
 OP1D_ADVEC_Q, OP1D_CALC_PU, OP1D_UN_PU, OP1D_ADVEC_P, OP1D_ADVEC_PU, OP1D_ADVEC_T, OP1D_PGF = range(7)
 (PEOP_CALC_PU, PEOP_CALC_PV, PEOP_UN_PU, PEOP_UN_PV, PEOP_AFLUX, PEOP_ADVEC_SIG, PEOP_ADVEC_M_PU, PEOP_GEOPOTENTIAL,
@@ -83,6 +84,7 @@ SYMBOLS = {
     "gcm_stats": (C.c_int, [_H, _dp, C.c_int, _dp]),
     "gcm_flux_limiter": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]),
     "gcm_polar_filter": (C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p]),
+    "gcm_get_intermediate": (C.c_int, [_H, C.c_int, C.c_void_p]),
     "gcm_set_ground": (C.c_int, [_H, C.c_void_p]),
     "gcm_get_ground": (C.c_int, [_H, C.c_void_p]),
     "gcm_grey_radiation": (C.c_int, [_H] + [C.c_double] * 4 + [_dp, _dp, C.c_void_p, C.c_void_p]),

@@ -148,6 +148,14 @@ class Core:
     def half_step(self, stage, dt):
         _check(lib.gcm_half_step(self._h, int(stage), float(dt)), self._h)
 
+    def get_intermediate(self, kind):
+        """parity tap (GCM_PE25D): spu, pit, p_n, phi or pgfu of the last half step, as the stage kernels
+        left them in the handle (gcm_get_intermediate; _lib.INT_*)"""
+        two_d = kind in (_lib.INT_PIT, _lib.INT_PN)
+        out = np.empty((self.H, self.W) if two_d else (self.L, self.H, self.W))
+        _check(lib.gcm_get_intermediate(self._h, int(kind), _ptr(out)), self._h)
+        return out
+
     def snapshot(self):
         """device-side copy of the current state (2-D models)"""
         _check(lib.gcm_snapshot(self._h), self._h)

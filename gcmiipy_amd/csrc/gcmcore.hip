@@ -1103,6 +1103,13 @@ int gcm_polar_filter(gcm_handle *h, int nlev, const double *in, double *out) {
     return pe25d_filter_field(h->pe, nlev, in, out, h->stream, &h->err);
 }
 
+int gcm_get_intermediate(gcm_handle *h, int kind, double *out) {
+    if (!h || !out) return GCM_ERR_ARG;
+    if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_get_intermediate: GCM_PE25D only");
+    if (h->cfg.device >= 0) HIPCHK(h, hipSetDevice(h->cfg.device));
+    return pe25d_intermediate(h->pe, kind, out, h->stream, &h->err);
+}
+
 int gcm_get_ground(gcm_handle *h, double *gt) {
     if (!h || !gt) return GCM_ERR_ARG;
     if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_get_ground: GCM_PE25D only");

@@ -31,6 +31,7 @@ int pe25d_half(Pe25d *m, int stage, double dt, hipStream_t s, std::string *err);
 size_t pe25d_halo_bytes(const Pe25d *m);
 int pe25d_halo_segments(Pe25d *m, bool pack, int side, void *dev_buf, SegCopy *c, std::string *err);
 int pe25d_ground(Pe25d *m, bool set, const double *in, double *out, hipStream_t s, std::string *err);
+int pe25d_intermediate(Pe25d *m, int kind, double *out, hipStream_t s, std::string *err);
 int pe25d_filter_field(Pe25d *m, int nlev, const double *in, double *out, hipStream_t s, std::string *err);
 int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, double t_sw, double albedo,
                     const double *lat, const double *lon, double *dTdt_host, double *dtg_host,

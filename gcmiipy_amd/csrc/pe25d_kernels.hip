@@ -471,6 +471,7 @@ struct Pe25d {
     int nseg = 1;                               // level segments of K4, chosen from the band's size
     int upd_rows = 7;                           // rows per workgroup of the row-group K4 (0: one-wave form)
     int cus = 256;
+    int last_stage_set = -1;                    // state set the last half step took its stage state from (gcm_get_intermediate)
     bool pit2d = true;                          // pit from the column sums K4 leaves (nseg == 1, row-group K4)
     int nseg_edge = 1;                          // bands: level segments of the EDGE rows' K4 launch (see half_t)
     bool cs_valid[3] = {false, false, false};   // the state set's column sums belong to its winds
@@ -913,6 +914,7 @@ template <typename T>
 static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1, hipStream_t s, int mode) {
     if (j1 <= j0) return;
     PeArgsT<T> a = make_args<T>(m, stage_set, out_set, dt);
+    m->last_stage_set = stage_set;
     const int W = m->W, L = m->L;
     const int ext = m->wrap ? 0 : 1;             // intermediates are also needed on row j1 (south)
     const size_t lds = filter_lds_bytes<T>(m);
@@ -1316,6 +1318,66 @@ static int filter_field_t(Pe25d *m, int nlev, const double *in, double *out, hip
         return GCM_ERR_HIP;
     }
     return GCM_OK;
+}
+
+// ---------------------------------------------------------------- parity tap: the stage's intermediates
+// phi on every level in the host layout [k][j][i], float64: the stored anchors on the even levels, the odd
+// levels stepped up from them with phi_up -- the expression K3 and K4 evaluate
+template <typename T>
+__global__ __launch_bounds__(256) void pe_phi_full_kernel(PeArgsT<T> a, double *out) {
+    __shared__ double tab[kExnerTabDoubles];
+    for (int n = threadIdx.x; n < kExnerTabDoubles; n += 256) tab[n] = a.exner_tab[n];
+    __syncthreads();
+    const int W = a.W, H = a.H, L = a.L;
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i >= W) return;
+    const long c3 = (long)j * L * W + i;
+    const T spc = a.sp[(long)j * W + i];
+    T phi_lo = T(0.0), t_lo = T(0.0), ex_lo = T(0.0);
+    for (int k = 0; k < L; ++k) {
+        const T t = a.st[c3 + (long)k * W];
+        const T ex = exner(spc * a.sig[k] + a.ptop, tab);
+        const T phi = (k & 1) ? phi_up(phi_lo, t_lo, t, ex_lo, ex) : a.phi[c3 + (long)k * W];
+        out[((long)k * H + j) * W + i] = (double)phi;
+        phi_lo = phi; t_lo = t; ex_lo = ex;
+    }
+}
+
+template <typename T>
+static int intermediate_t(Pe25d *m, int kind, double *out, hipStream_t s, std::string *err) {
+    PeBufs<T> &B = bufs<T>(m);
+    const int W = m->W, H = m->H, L = m->L;
+    const T *src = nullptr;
+    int lev = L;
+    switch (kind) {
+        case GCM_INT_SPU: src = B.spu; break;
+        case GCM_INT_PGFU: src = B.pgfu; break;
+        case GCM_INT_PIT: src = B.pit; lev = 1; break;
+        case GCM_INT_PN: src = B.pn; lev = 1; break;
+        case GCM_INT_PHI: break;
+        default: *err = "gcm_get_intermediate: unknown kind"; return GCM_ERR_ARG;
+    }
+    if (kind == GCM_INT_PHI) {
+        PeArgsT<T> a = make_args<T>(m, m->last_stage_set, m->last_stage_set, 0.0);
+        hipLaunchKernelGGL(pe_phi_full_kernel<T>, dim3((W + 255) / 256, H), dim3(256), 0, s, a, m->stage3);
+    } else {
+        hipLaunchKernelGGL(pe_to_host_kernel<T>, dim3(1024), dim3(256), 0, s, m->stage3, src, W, H, lev);
+    }
+    hipError_t e = hipMemcpyAsync(out, m->stage3, sizeof(double) * (size_t)lev * H * W, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        *err = std::string("gcm_get_intermediate: ") + hipGetErrorString(e);
+        return GCM_ERR_HIP;
+    }
+    return GCM_OK;
+}
+
+int pe25d_intermediate(Pe25d *m, int kind, double *out, hipStream_t s, std::string *err) {
+    if (!m->wrap) { *err = "gcm_get_intermediate: single band only"; return GCM_ERR_UNSUPPORTED; }
+    if (m->last_stage_set < 0) { *err = "gcm_get_intermediate: no half step taken yet"; return GCM_ERR_STATE; }
+    if (m->aux) (void)hipStreamSynchronize(m->aux);
+    return m->f32 ? intermediate_t<float>(m, kind, out, s, err) : intermediate_t<double>(m, kind, out, s, err);
 }
 
 int pe25d_filter_field(Pe25d *m, int nlev, const double *in, double *out, hipStream_t s, std::string *err) {

@@ -191,6 +191,17 @@ int gcm_energy(gcm_handle *h, const double *area, int area_len, double *out4);
  * damping of nlev <= layers levels of a field on the handle's grid, host [nlev][H][W] float64 in and
  * out (may alias).  Rows are filtered with the multiplier of their global latitude.              */
 int gcm_polar_filter(gcm_handle *h, int nlev, const double *in, double *out);
+/* Parity tap (GCM_PE25D, single band): the intermediates of the LAST gcm_half_step as the stage kernels
+ * themselves left them in the handle -- not a recomputation -- so that a mistake inside K1 / K2 / K3 shows
+ * as a wrong intermediate, not only as a wrong stage output.  Host float64, reference layouts.
+ *   GCM_INT_SPU   [L][H][W]  spu = arakawa_1977(calc_pu(sp, su))                 dynamics.py:186-190
+ *   GCM_INT_PIT   [H][W]     pit = sum_k conv (from the 2-D column sums)         dynamics.py:35-40
+ *   GCM_INT_PN    [H][W]     p_n = p - pit dt                                    dynamics.py:194
+ *   GCM_INT_PHI   [L][H][W]  compute_geopotential: the stored anchors on the even levels, the odd levels
+ *                            rebuilt from them exactly as K3 and K4 do (phi_up)  dynamics.py:111-143
+ *   GCM_INT_PGFU  [L][H][W]  arakawa_1977(pgu + phiu)                            dynamics.py:147-171,203      */
+typedef enum { GCM_INT_SPU = 0, GCM_INT_PIT = 1, GCM_INT_PN = 2, GCM_INT_PHI = 3, GCM_INT_PGFU = 4 } gcm_intermediate;
+int gcm_get_intermediate(gcm_handle *h, int kind, double *out);
 int gcm_set_ground(gcm_handle *h, const double *gt);
 int gcm_get_ground(gcm_handle *h, double *gt);
 int gcm_grey_radiation(gcm_handle *h, double utc, double t_lw, double t_sw, double albedo,

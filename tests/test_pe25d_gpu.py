@@ -490,3 +490,69 @@ def test_fp32_bands_in_process(g):
     for f in range(5):
         got = np.concatenate([p_[f] for p_ in parts], axis=0 if f == 0 else 1)
         assert np.array_equal(got, want[f]), f             # same fp32 arithmetic per row: bit-identical
+
+
+def _tap(c, g):
+    L = g._lib
+    return {"spu": c.get_intermediate(L.INT_SPU), "pit": c.get_intermediate(L.INT_PIT), "p_n": c.get_intermediate(L.INT_PN),
+            "phi": c.get_intermediate(L.INT_PHI), "pgfu": c.get_intermediate(L.INT_PGFU)}
+
+
+def test_hot_path_intermediates_vs_golden(g):
+    """G7: spu, pit, p_n, phi and pgfu as the STAGE kernels K1 / K2a / K2b' / K3 leave them in the handle
+    (gcm_get_intermediate: a tap, not a recomputation), predictor and corrector, against the reference's
+    own intermediates (dynamics.py:35-46,111-171,186-205) -- a mistake inside the fused stage is localised
+    by the intermediate that fails, not only by the stage output"""
+    from gcmiipy_amd import geometry
+    d = golden("g7_half_step")
+    L, H, W = d["u0"].shape
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    geom.heightmap[...] = d["heightmap"]
+    c = g.Core(g._lib.PE25D, W, H, L, geom=geom)
+    with pytest.raises(g.GcmError):
+        c.get_intermediate(g._lib.INT_SPU)                       # no half step yet
+    c.set_state(*[d[k + "0"] for k in "puvtq"])
+    for stage, name in ((0, "pred"), (1, "corr")):
+        c.half_step(stage, float(d["dt"]))
+        got = _tap(c, g)
+        for k in ("spu", "pit", "p_n", "phi", "pgfu"):
+            e = rel_err(got[k], d["%s_%s" % (name, k)])
+            assert e < TOL, (name, k, e)
+    with pytest.raises(ValueError):
+        c.get_intermediate(99)
+    c.close()
+
+
+def test_hot_path_intermediates_vs_oracle_1440_columns(g):
+    """the same tap at the production row length (1440 columns: the composite-radix transform, the looping
+    K1 with pit in its launch, K3's batched sweep), 8 rows x 24 levels, predictor and corrector vs the oracle"""
+    from gcmiipy_amd import geometry
+    from oracle import dynamics as od, geometry as ogeo
+    H, W, L = 8, 1440, 24
+    rng = np.random.default_rng(21)
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    og = ogeo.gen_geometry(H, W, L, sig_func=ogeo.manabe_sig)
+    geom.heightmap[...] = og.heightmap[...] = 30 * rng.random((H, W))
+    p = 1e5 + 10 * rng.standard_normal((H, W))
+    u, v = rng.standard_normal((L, H, W)), rng.standard_normal((L, H, W))
+    v[:, -1, :] = 0
+    t = (300 + rng.standard_normal((L, H, W))) * ((1e5 / (p * og.sig + og.ptop)) ** (287.0 / 1004.0))
+    q = 3e-6 * (1 + 0.1 * rng.random((L, H, W)))
+    base, dt = (p, u, v, t, q), 30.0
+    c = g.Core(g._lib.PE25D, W, H, L, geom=geom)
+    c.set_state(*base)
+    stage_state = base
+    for stage in (0, 1):
+        tap = {}
+        out = od.half_timestep(*base, *stage_state, dt, og, _tap=tap)
+        tap["phi"] = od.compute_geopotential(stage_state[0], stage_state[3], og)
+        tap["p_n"] = out[0]
+        c.half_step(stage, dt)
+        got = _tap(c, g)
+        for k in ("spu", "pit", "p_n", "phi", "pgfu"):
+            e = rel_err(got[k], tap[k])
+            assert e < TOL, (stage, k, e)
+        stage_state = out
+    for a, b, k in zip(c.get_state(), stage_state, "puvtq"):
+        assert rel_err(a, b) < TOL, k
+    c.close()
