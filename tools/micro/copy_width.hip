@@ -1,0 +1,75 @@
+// What a plain streaming copy reaches on MI355X by access width and pattern (the kernels of this library
+// move 8 bytes per lane): hipcc --offload-arch=gfx950 -O3 copy_width.hip -o copy_width
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+template <typename V>
+__global__ __launch_bounds__(256) void copy_k(V *__restrict__ dst, const V *__restrict__ src, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+// the access pattern of sw2d_fused_kernel: one wave per workgroup marches down a 64-column strip of NF
+// arrays [H][W], reading a row of each and writing a row of each (one row ahead in flight)
+template <int NF, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void strip_k(double *const *dst, const double *const *src, int W, int H, int rows_per_band) {
+    const int strips = W / (64 * WAVES);
+    const int band = blockIdx.x / strips, i = (blockIdx.x % strips) * 64 * WAVES + threadIdx.x;
+    const int j0 = band * rows_per_band, j1 = min(H, j0 + rows_per_band);
+    double cur[NF], nxt[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) cur[f] = src[f][(long)j0 * W + i];
+    for (int j = j0; j < j1; ++j) {
+        const int jn = min(j + 1, j1 - 1);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) nxt[f] = src[f][(long)jn * W + i];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) dst[f][(long)j * W + i] = cur[f] * 1.0000001;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) cur[f] = nxt[f];
+    }
+}
+int main() {
+    const int W = 4096, H = 2048, NF = 5;
+    const long n = (long)W * H;            // doubles per field
+    std::vector<double *> s(NF), d(NF);
+    double *sall, *dall;
+    CK(hipMalloc(&sall, sizeof(double) * n * NF)); CK(hipMalloc(&dall, sizeof(double) * n * NF));
+    CK(hipMemset(sall, 0x11, sizeof(double) * n * NF));
+    for (int f = 0; f < NF; ++f) { s[f] = sall + f * n; d[f] = dall + f * n; }
+    double **ds, **dd;
+    CK(hipMalloc(&ds, sizeof(double *) * NF)); CK(hipMalloc(&dd, sizeof(double *) * NF));
+    CK(hipMemcpy(ds, s.data(), sizeof(double *) * NF, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dd, d.data(), sizeof(double *) * NF, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double bytes = 2.0 * sizeof(double) * n * NF;
+    auto time = [&](const char *name, auto &&launch) -> int {
+        for (int w = 0; w < 20; ++w) launch();
+        CK(hipEventRecord(e0, 0));
+        const int reps = 200;
+        for (int r = 0; r < reps; ++r) launch();
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-62s %7.3f ms  %6.2f TB/s\n", name, ms / reps, bytes * reps / (ms * 1e-3) / 1e12);
+        return 0;
+    };
+    for (int blocks : {2048, 8192, 32768}) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "grid-stride copy,  4 B per lane, %5d workgroups", blocks);
+        time(nm, [&] { hipLaunchKernelGGL(copy_k<float>, dim3(blocks), dim3(256), 0, 0, (float *)dall, (const float *)sall, n * NF * 2); });
+        snprintf(nm, sizeof nm, "grid-stride copy,  8 B per lane, %5d workgroups", blocks);
+        time(nm, [&] { hipLaunchKernelGGL(copy_k<double>, dim3(blocks), dim3(256), 0, 0, dall, (const double *)sall, n * NF); });
+        snprintf(nm, sizeof nm, "grid-stride copy, 16 B per lane, %5d workgroups", blocks);
+        time(nm, [&] { hipLaunchKernelGGL(copy_k<double2>, dim3(blocks), dim3(256), 0, 0, (double2 *)dall, (const double2 *)sall, n * NF / 2); });
+    }
+    for (int rpb : {47, 94}) {
+        char nm[128];
+        snprintf(nm, sizeof nm, "strip march (sw2d_fused pattern), 5 + 5 arrays, %4d rows per band", rpb);
+        const int bands = (H + rpb - 1) / rpb;
+        time(nm, [&] { hipLaunchKernelGGL((strip_k<NF, 1>), dim3((W / 64) * bands), dim3(64), 0, 0, dd, (const double *const *)ds, W, H, rpb); });
+        snprintf(nm, sizeof nm, "  the same, 2 adjacent strips per workgroup (128 threads), %4d rows", rpb);
+        time(nm, [&] { hipLaunchKernelGGL((strip_k<NF, 2>), dim3((W / 128) * bands), dim3(128), 0, 0, dd, (const double *const *)ds, W, H, rpb); });
+        snprintf(nm, sizeof nm, "  the same, 4 adjacent strips per workgroup (256 threads), %4d rows", rpb);
+        time(nm, [&] { hipLaunchKernelGGL((strip_k<NF, 4>), dim3((W / 256) * bands), dim3(256), 0, 0, dd, (const double *const *)ds, W, H, rpb); });
+    }
+    return 0;
+}
