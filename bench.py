@@ -34,7 +34,7 @@ L2_BYTES = 32 * 2 ** 20
 SETTLE_S = float(os.environ.get("GCM_BENCH_SETTLE_S", "0.15"))   # untimed pre-conditioning before warm-up (see run_workload)
 MIN_TIMED_S = float(os.environ.get("GCM_BENCH_MIN_TIMED_S", "0.5"))   # the K-step block is repeated until this much is timed
 MAX_BLOCKS = 400
-PROFILE_ROUND = "r02"     # profiles/<round>/traffic.json: PMC passes of this same command (tools/tools_prof.sh)
+PROFILE_ROUND = "r03"     # profiles/<round>/traffic.json: PMC passes of this same command (tools/tools_prof.sh)
 
 WORKLOADS = {
     # name: (description, H, W, L, model, tracer, bytes per cell-update = 2 * fields * 8, dt)
@@ -346,7 +346,18 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
             lb.run(nlb, dt)
             e1.record()
             torch.cuda.synchronize()
+            # what the HOST needs to queue a step when no call can block on a full queue: a few steps queued
+            # behind one long spin kernel (torch.cuda._sleep, ~40 ms).  "host_queue_ms_per_step" above it is
+            # taken on a busy device and also counts the time the queue holds the host back.
+            nq = max(k, 4) // k * k
+            torch.cuda.synchronize()
+            torch.cuda._sleep(int(40e-3 * 2.0e9))
+            tq = time.perf_counter()
+            lb.run(nq, dt)
+            host_idle = (time.perf_counter() - tq) * 1e3 / nq
+            torch.cuda.synchronize()
             res["diagnostics"] = {"host_queue_ms_per_step": t_queued / steps * 1e3,
+                                  "host_queue_ms_per_step_idle_device": host_idle,
                                   "band_ms_per_step_local_exchange": e0.elapsed_time(e1) / nlb,
                                   "rank": rank}
         if world == 1 and want_kernel:
@@ -361,10 +372,10 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
             kiso = None
             launches = 1
             if model == "PE25D":
-                # one Euler stage = five launches (spu filter, pit2d, geopot, pgf filter, update) on two
+                # one Euler stage = four launches (spu filter with pit in its launch, geopot, pgf filter, update) on two
                 # streams; the roofline entry is the WHOLE stage: half of the step's algorithmic bytes over
                 # half of the step's device time (HIP events around the timed blocks)
-                kname, kms, launches = ("pe25d stage: pe_spu_filter + pe_pit2d + pe_geopot + pe_pgf_filter + pe_update_rows"
+                kname, kms, launches = ("pe25d stage: pe_spu_filter_loop (+ pit) + pe_geopot + pe_pgf_filter + pe_update_rows"
                                         + (" (+ half of pe_radiation)" if phys else "")), region["ms"] / launches_timed / 2, 2
             elif variant == "fused" and model == "SW2D":
                 # plain shallow water steps in pairs (one launch = two steps): per-step figures

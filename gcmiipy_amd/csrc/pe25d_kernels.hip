@@ -46,7 +46,9 @@ __device__ __forceinline__ T column_sum(const T *col, const T *dsig, int L, int 
 }
 // LMAX > 0: L <= LMAX and the per-level stp stay in registers (loops unrolled over LMAX; no LDS
 // park, so the occupancy is not limited by it); LMAX == 0: any L, stp parked in LDS
-template <typename T, int LMAX = 0>
+// CS: the launch also forms the column sums of its rows (a band's ghost rows; a template parameter, because the
+// mere presence of that code in the kernel cost the plain instantiation 40 % of its speed)
+template <typename T, int LMAX = 0, bool CS = false>
 __global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
     __shared__ double tab[kExnerTabDoubles];
     extern __shared__ unsigned char park_raw[];
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
     const int i = (tile - jrel * iblocks) * kColThreads + threadIdx.x;
     const int j = jrel < na ? a.j0 + jrel : a.jb0 + (jrel - na);
     if (i >= W) return;
-    if (a.cs_rows) {
+    if (CS) {
         // a band's ghost rows in one launch: their column sums too (see pe_colsum_kernel)
         a.scs_u[ix.r2(j) + i] = column_sum(a.su + ix.r3(j) + i, a.dsig, L, W);
         a.scs_v[ix.r2(j) + i] = column_sum(a.sv + ix.r3(j) + i, a.dsig, L, W);
@@ -618,6 +620,8 @@ static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
                             (int)(filter_lds_bytes<T>(m) + sizeof(T) * (size_t)W)) != hipSuccess ||
         hipFuncSetAttribute((const void *)pe_geopot_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(L * kColThreads * sizeof(T))) != hipSuccess ||
+        hipFuncSetAttribute((const void *)pe_geopot_kernel<T, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(L * kColThreads * sizeof(T))) != hipSuccess ||
         hipFuncSetAttribute((const void *)pe_radiation_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(sizeof(double) * (size_t)L * kRadThreads)) != hipSuccess ||
         hipFuncSetAttribute((const void *)update_rows_kernel_for<T>(7, true), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -942,9 +946,16 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         if (rows <= 0) return;
         const long tiles = (long)((W + kColThreads - 1) / kColThreads) * rows;
         const dim3 gg((unsigned)((tiles + 7) / 8 * 8));
-        if (L <= 24) hipLaunchKernelGGL((pe_geopot_kernel<T, 24>), gg, dim3(kColThreads), 0, st, c);
-        else if (L <= 40) hipLaunchKernelGGL((pe_geopot_kernel<T, 40>), gg, dim3(kColThreads), 0, st, c);
-        else hipLaunchKernelGGL((pe_geopot_kernel<T, 0>), gg, dim3(kColThreads), sizeof(T) * (size_t)L * kColThreads, st, c);
+        const size_t park = sizeof(T) * (size_t)L * kColThreads;
+        if (c.cs_rows) {
+            if (L <= 24) hipLaunchKernelGGL((pe_geopot_kernel<T, 24, true>), gg, dim3(kColThreads), 0, st, c);
+            else if (L <= 40) hipLaunchKernelGGL((pe_geopot_kernel<T, 40, true>), gg, dim3(kColThreads), 0, st, c);
+            else hipLaunchKernelGGL((pe_geopot_kernel<T, 0, true>), gg, dim3(kColThreads), park, st, c);
+        } else {
+            if (L <= 24) hipLaunchKernelGGL((pe_geopot_kernel<T, 24>), gg, dim3(kColThreads), 0, st, c);
+            else if (L <= 40) hipLaunchKernelGGL((pe_geopot_kernel<T, 40>), gg, dim3(kColThreads), 0, st, c);
+            else hipLaunchKernelGGL((pe_geopot_kernel<T, 0>), gg, dim3(kColThreads), park, st, c);
+        }
     };
     if (mode != 2) {
         a.j0 = j0;
