@@ -764,6 +764,7 @@ static int band_step_pe(gcm_handle *h, double dt) {
         if (ax) {
             if ((rc = band_post(h, false, ax))) return rc;
             if ((rc = gcm_halo_unpack2(h, h->xch.recv_north, h->xch.recv_south, ax))) return rc;
+            pe25d_prep_ghost_rows(h->pe);
             h->join_pending = true;
         }
         if ((rc = pe25d_step_phase(h->pe, 2 * stage + 1, dt, h->stream, &h->err))) return rc;

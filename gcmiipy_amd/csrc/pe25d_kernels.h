@@ -24,6 +24,7 @@ int pe25d_step_part(Pe25d *m, int part, double dt, hipStream_t s, std::string *e
 int pe25d_step_phase(Pe25d *m, int phase, double dt, hipStream_t s, std::string *err);
 int pe25d_set_halo_buffers(Pe25d *m, void *north, void *south, hipStream_t s, std::string *err);
 int pe25d_wait_edges(Pe25d *m, hipStream_t s, std::string *err);
+void pe25d_prep_ghost_rows(Pe25d *m);       // gcm_band_run: behind the unpack on the second stream
 hipStream_t pe25d_aux_stream(const Pe25d *m);
 // a new non-blocking stream that demonstrably runs beside `main` (and `other`, may be null)
 hipStream_t concurrent_stream(hipStream_t main, hipStream_t other);

@@ -474,6 +474,7 @@ struct Pe25d {
     int upd_rows = 7;                           // rows per workgroup of the row-group K4 (0: one-wave form)
     int cus = 256;
     int last_stage_set = -1;                    // state set the last half step took its stage state from (gcm_get_intermediate)
+    int ghost_ready = -1;                       // state set whose ghost rows' column sums and anchors are queued already (pe25d_prep_ghost_rows)
     bool pit2d = true;                          // pit from the column sums K4 leaves (nseg == 1, row-group K4)
     int nseg_edge = 1;                          // bands: level segments of the EDGE rows' K4 launch (see half_t)
     bool cs_valid[3] = {false, false, false};   // the state set's column sums belong to its winds
@@ -859,6 +860,7 @@ int pe25d_set(Pe25d *m, bool star, const double *p, const double *u, const doubl
     const double *in[GCM_NFIELDS] = {p, u, v, t, q};
     int rc = xfer(m, star ? 2 : m->cur_i, true, in, nullptr, s, err);
     if (u || v) m->cs_valid[star ? 2 : m->cur_i] = false;
+    m->ghost_ready = -1;
     if (rc == GCM_OK) m->star_valid = star;
     return rc;
 }
@@ -909,6 +911,57 @@ static bool async_edges(const Pe25d *m) { return m->send_buf[0] && m->send_buf[1
 
 static void tick(Pe25d *m, hipStream_t s) {
     if (m->ev && m->ev_used && *m->ev_used < m->ev->size()) (void)hipEventRecord((*m->ev)[(*m->ev_used)++], s);
+}
+
+// Column sums and geopotential anchors of the stage state's rows that no kernel of the previous stage left:
+// all rows' sums of a freshly set state, else a band's two ghost rows next to its own (pit of row j takes V of
+// row j - 1; the intermediates extend to row j1) -- and, in the same launch, the geopotential of a band's south
+// ghost row (K4 of row j1 - 1 takes phi of row j1).  `a`: the stage's arguments with j0 / j1 set.
+template <typename T>
+static void prep_rows(Pe25d *m, const PeArgsT<T> &a, int stage_set, bool p2, int j1, int ext, hipStream_t sb) {
+    const int W = m->W, L = m->L;
+    const auto geopot = [&](const PeArgsT<T> &c, hipStream_t st) {
+        const int rows = (c.j1 - c.j0) + (c.jb1 - c.jb0);
+        if (rows <= 0) return;
+        const long tiles = (long)((W + kColThreads - 1) / kColThreads) * rows;
+        const dim3 gg((unsigned)((tiles + 7) / 8 * 8));
+        const size_t park = sizeof(T) * (size_t)L * kColThreads;
+        if (c.cs_rows) {
+            if (L <= 24) hipLaunchKernelGGL((pe_geopot_kernel<T, 24, true>), gg, dim3(kColThreads), 0, st, c);
+            else if (L <= 40) hipLaunchKernelGGL((pe_geopot_kernel<T, 40, true>), gg, dim3(kColThreads), 0, st, c);
+            else hipLaunchKernelGGL((pe_geopot_kernel<T, 0, true>), gg, dim3(kColThreads), park, st, c);
+        } else {
+            if (L <= 24) hipLaunchKernelGGL((pe_geopot_kernel<T, 24>), gg, dim3(kColThreads), 0, st, c);
+            else if (L <= 40) hipLaunchKernelGGL((pe_geopot_kernel<T, 40>), gg, dim3(kColThreads), 0, st, c);
+            else hipLaunchKernelGGL((pe_geopot_kernel<T, 0>), gg, dim3(kColThreads), park, st, c);
+        }
+    };
+    PeArgsT<T> c = a;
+    c.jb0 = c.jb1 = 0;
+    bool fresh = false;
+    if (!p2) {
+        c.j0 = j1; c.j1 = j1 + ext;
+    } else if (!m->cs_valid[stage_set]) {
+        c.j0 = m->wrap ? 0 : -1;
+        c.j1 = m->H + ext;
+        m->cs_valid[stage_set] = true;
+        fresh = true;
+    } else if (m->nseg_edge > 1) {                   // + the own edge rows (marched in segments: no sums from K4)
+        c.j0 = -1; c.j1 = kGhost;
+        c.jb0 = m->H - kGhost; c.jb1 = m->H + 1;
+    } else {
+        c.j0 = -1; c.j1 = 0;
+        c.jb0 = m->H; c.jb1 = m->H + 1;
+    }
+    c.cs_rows = p2 ? 1 : 0;
+    c.geo_j0 = j1; c.geo_j1 = j1 + ext;
+    if (fresh && (c.j1 - c.j0) > 8) {
+        // a whole state's sums: the plain column-sum kernel (no thermodynamics compiled in), then the ghost row
+        hipLaunchKernelGGL(pe_colsum_kernel<T>, dim3((unsigned)((W + 255) / 256) * (c.j1 - c.j0)), dim3(256), 0, sb, c);
+        c.cs_rows = 0;
+        c.j0 = j1; c.j1 = j1 + ext;
+    }
+    if (!m->wrap || (fresh && c.cs_rows)) geopot(c, sb);
 }
 
 // one Euler stage over rows [j0, j1): state `stage_set` -> `out_set`, base = current.
@@ -965,38 +1018,8 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
             (void)hipEventRecord(m->ev_fork, s);
             (void)hipStreamWaitEvent(m->aux, m->ev_fork, 0);
         }
-        {
-            // rows whose column sums no K4 left: all of a freshly set state, else a band's two ghost rows
-            // next to its own (pit of row j takes V of row j - 1; the intermediates extend to row j1) --
-            // and, in the same launch, the geopotential of a band's south ghost row (K4 of row j1 - 1 takes
-            // phi of row j1)
-            PeArgsT<T> c = a;
-            c.jb0 = c.jb1 = 0;
-            bool fresh = false;
-            if (!p2) {
-                c.j0 = j1; c.j1 = j1 + ext;
-            } else if (!m->cs_valid[stage_set]) {
-                c.j0 = m->wrap ? 0 : -1;
-                c.j1 = m->H + ext;
-                m->cs_valid[stage_set] = true;
-                fresh = true;
-            } else if (m->nseg_edge > 1) {                   // + the own edge rows (marched in segments: no sums from K4)
-                c.j0 = -1; c.j1 = kGhost;
-                c.jb0 = m->H - kGhost; c.jb1 = m->H + 1;
-            } else {
-                c.j0 = -1; c.j1 = 0;
-                c.jb0 = m->H; c.jb1 = m->H + 1;
-            }
-            c.cs_rows = p2 ? 1 : 0;
-            c.geo_j0 = j1; c.geo_j1 = j1 + ext;
-            if (fresh && (c.j1 - c.j0) > 8) {
-                // a whole state's sums: the plain column-sum kernel (no thermodynamics compiled in), then the ghost row
-                hipLaunchKernelGGL(pe_colsum_kernel<T>, dim3((unsigned)((W + 255) / 256) * (c.j1 - c.j0)), dim3(256), 0, sb, c);
-                c.cs_rows = 0;
-                c.j0 = j1; c.j1 = j1 + ext;
-            }
-            if (!m->wrap || (fresh && c.cs_rows)) geopot(c, sb);
-        }
+        if (m->ghost_ready == stage_set && (!p2 || m->cs_valid[stage_set])) m->ghost_ready = -1;      // queued behind the unpack already
+        else prep_rows<T>(m, a, stage_set, p2, j1, ext, sb);
         static const bool no_loop = getenv("GCM_PE_FILTER_NO_LOOP") != nullptr;        // diagnostic: one workgroup per pair
         const FilterLoopKernel<T> k1 = (m->cfg.filter && W > 1 && !no_loop) ? spu_filter_loop_kernel_for<T>(m->cplan) : nullptr;
         bool pit_done = false;
@@ -1117,6 +1140,28 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
 static void half(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1, hipStream_t s, int mode = 0) {
     if (m->f32) half_t<float>(m, stage_set, out_set, dt, j0, j1, s, mode);
     else half_t<double>(m, stage_set, out_set, dt, j0, j1, s, mode);
+}
+
+// gcm_band_run, right behind the unpack on the second stream: the ghost rows that have just arrived belong to
+// the state the NEXT stage reads; their column sums and the south ghost row's geopotential depend on nothing
+// else, so they are queued here -- beside the interior rows' K4 of the stage still running -- instead of at the
+// head of the next stage's chain B, where they were 17 us in front of K1.
+void pe25d_prep_ghost_rows(Pe25d *m) {
+    if (m->wrap || !m->aux) return;
+    int set = m->star_valid ? 2 : m->cur_i;                      // the set the unpack has just filled (halo_t)
+    if (m->pack_set >= 0 && m->pack_set != 2) set = m->pack_set;
+    const bool p2 = m->pit2d && m->nseg == 1 && m->upd_rows > 0;
+    if (p2 && !m->cs_valid[set]) return;                         // (a fresh state: the stage does all rows itself)
+    if (m->f32) {
+        PeArgsT<float> a = make_args<float>(m, set, set, 0.0);
+        a.j0 = 0; a.j1 = m->H + 1;
+        prep_rows<float>(m, a, set, p2, m->H, 1, m->aux);
+    } else {
+        PeArgsT<double> a = make_args<double>(m, set, set, 0.0);
+        a.j0 = 0; a.j1 = m->H + 1;
+        prep_rows<double>(m, a, set, p2, m->H, 1, m->aux);
+    }
+    m->ghost_ready = set;
 }
 
 int pe25d_half(Pe25d *m, int stage, double dt, hipStream_t s, std::string *err) {
@@ -1438,6 +1483,7 @@ static int radiation_launch(Pe25d *m, bool apply, double dt, double hour_angle, 
     r.dTdt = B.pgfu; r.dtg = B.pit;
     r.hour_angle = hour_angle;
     r.albedo = albedo; r.dt = dt; r.apply = apply ? 1 : 0;
+    if (apply) m->ghost_ready = -1;                        // theta changes in place
     {
         const dim3 gg((W + kRadThreads - 1) / kRadThreads, H);
         T *th = B.st[m->cur_i][GCM_T];
