@@ -86,12 +86,18 @@ static int fail(gcm_handle *h, int code, const std::string &msg) {
 }
 
 static int alloc_field(gcm_handle *h, double **p) {
+    // Every array starts a different multiple of 256 B past its (2 MiB-aligned) allocation: rows of a
+    // power-of-two width would otherwise put the same (row, column) of all fields on the same HBM channel and
+    // bank, and a wave of the fused kernel touches that element of ten arrays per row (tools/micro/copy_width.hip:
+    // the bare access pattern moves 4-6 % faster with the arrays skewed).  GCM_ALLOC_SKEW=0 switches it off.
+    static const long skew_unit = getenv("GCM_ALLOC_SKEW") ? atol(getenv("GCM_ALLOC_SKEW")) : 256;
     const size_t n = (size_t)(h->H + 2 * h->G) * h->W;
+    const size_t skew = (size_t)(skew_unit > 0 ? skew_unit : 0) * (h->allocs.size() % 16) / sizeof(double);
     void *d = nullptr;
-    HIPCHK(h, hipMalloc(&d, n * sizeof(double)));
-    HIPCHK(h, hipMemsetAsync(d, 0, n * sizeof(double), h->stream));
+    HIPCHK(h, hipMalloc(&d, (n + skew) * sizeof(double)));
+    HIPCHK(h, hipMemsetAsync(d, 0, (n + skew) * sizeof(double), h->stream));
     h->allocs.push_back(d);
-    *p = (double *)d + (size_t)h->G * h->W;
+    *p = (double *)d + skew + (size_t)h->G * h->W;
     return GCM_OK;
 }
 

@@ -33,8 +33,9 @@ int main() {
     const long n = (long)W * H;            // doubles per field
     std::vector<double *> s(NF), d(NF);
     double *sall, *dall;
-    CK(hipMalloc(&sall, sizeof(double) * n * NF)); CK(hipMalloc(&dall, sizeof(double) * n * NF));
-    CK(hipMemset(sall, 0x11, sizeof(double) * n * NF));
+    const long slack = 1 << 20;            // doubles of slack per array for the skew experiments
+    CK(hipMalloc(&sall, sizeof(double) * (n + slack) * NF)); CK(hipMalloc(&dall, sizeof(double) * (n + slack) * NF));
+    CK(hipMemset(sall, 0x11, sizeof(double) * (n + slack) * NF));
     for (int f = 0; f < NF; ++f) { s[f] = sall + f * n; d[f] = dall + f * n; }
     double **ds, **dd;
     CK(hipMalloc(&ds, sizeof(double *) * NF)); CK(hipMalloc(&dd, sizeof(double *) * NF));
@@ -61,7 +62,21 @@ int main() {
         snprintf(nm, sizeof nm, "grid-stride copy, 16 B per lane, %5d workgroups", blocks);
         time(nm, [&] { hipLaunchKernelGGL(copy_k<double2>, dim3(blocks), dim3(256), 0, 0, (double2 *)dall, (const double2 *)sall, n * NF / 2); });
     }
-    for (int rpb : {47, 94}) {
+    // the same with the arrays skewed against each other: array f starts skew * f (src) / skew * (f + NF) (dst)
+    // bytes past its power-of-two-aligned position
+    for (long skew : {0L, 256L, 512L, 4096L, 4096L + 256L, 65536L + 4096L + 256L, 1048576L + 4096L + 256L}) {
+        for (int f = 0; f < NF; ++f) { s[f] = sall + f * n + skew / 8 * f; d[f] = dall + f * n + skew / 8 * (f + NF); }
+        CK(hipMemcpy(ds, s.data(), sizeof(double *) * NF, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dd, d.data(), sizeof(double *) * NF, hipMemcpyHostToDevice));
+        char nm[128];
+        snprintf(nm, sizeof nm, "strip march, 47 rows per band, arrays skewed by %8ld B each", skew);
+        const int bands = (H + 46) / 47;
+        time(nm, [&] { hipLaunchKernelGGL((strip_k<NF, 1>), dim3((W / 64) * bands), dim3(64), 0, 0, dd, (const double *const *)ds, W, H, 47); });
+    }
+    for (int f = 0; f < NF; ++f) { s[f] = sall + f * n; d[f] = dall + f * n; }
+    CK(hipMemcpy(ds, s.data(), sizeof(double *) * NF, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dd, d.data(), sizeof(double *) * NF, hipMemcpyHostToDevice));
+    for (int rpb : {47}) {
         char nm[128];
         snprintf(nm, sizeof nm, "strip march (sw2d_fused pattern), 5 + 5 arrays, %4d rows per band", rpb);
         const int bands = (H + rpb - 1) / rpb;
