@@ -162,9 +162,7 @@ template <typename T> FilterKernel<T> spu_filter_kernel_for(const SuperPlan &P);
 template <typename T> FilterLoopKernel<T> spu_filter_loop_kernel_for(const SuperPlan &P);   // pe25d_k1.h (null: no looping form)
 template <typename T> FilterKernel<T> pgf_filter_kernel_for(const SuperPlan &P);            // pe25d_k3.h
 template <typename T> FilterKernel<T> pit2d_kernel_for(const SuperPlan &P);                 // pe25d_k3.h
-template <typename T> FilterKernel<T> update_kernel_for();                                  // pe25d_k4.h, one-wave form
 template <typename T> FilterKernel<T> update_rows_kernel_for(int rows_per_group, bool same);  // pe25d_k4.h (R = 3 or 7)
-constexpr int kUpdThreads = 64;   // one-wave update kernel: one wave per workgroup packs the rounds of a short band best (256: +2.5 %)
 constexpr int kUpdCols = 62;      // row-group update kernel: columns a wave produces (lanes 0 and 63 carry the halo columns)
 constexpr int kFftThreads = 256;  // generic filter path; the composite path sizes the workgroup from its plan
 

@@ -1,210 +1,14 @@
-// K4 of GCM_PE25D (see pe25d_kernels.hip): the update kernels (one-wave form and row-group form) and
-// their pickers.  Included by pe25d_k4_f64.hip / pe25d_k4_f32.hip only.
+// K4 of GCM_PE25D (see pe25d_kernels.hip): the update kernel and its picker.  Included by pe25d_k4_f64.hip / pe25d_k4_f32.hip only.
 #pragma once
 #include "pe25d_dev.h"
 
 namespace gcm {
 
 // ---------------------------------------------------------------- K4: update
-// One thread per (j, i) column marching up the levels: the k-1 / k / k+1 values of the stage
-// winds, theta, q and sigma-dot rotate through registers, so only the horizontal neighbours
-// are loaded per level.  Tiles (row, 64-column block) are dealt to the 8 XCDs in contiguous
-// runs of rows (as sw2d_fused_kernel does): the blocks resident on one XCD work on adjacent
-// rows at about the same level, so the j+-1 re-reads hit that XCD's L2.
-template <typename T>
-__global__ __launch_bounds__(kUpdThreads) void pe_update_kernel(PeArgsT<T> a) {
-    __shared__ double tab[kExnerTabDoubles];
-    for (int n = threadIdx.x; n < kExnerTabDoubles; n += kUpdThreads) tab[n] = a.exner_tab[n];
-    __syncthreads();
-    const Idx ix{a.W, a.H, a.L, a.wrap};
-    const int W = a.W, L = a.L;
-    const int iblocks = (W + kUpdThreads - 1) / kUpdThreads;
-    const int per_xcd = gridDim.x / 8;
-    const int tile = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-    // tile = ((row, level segment), column block); rows come from [j0, j1) then [jb0, jb1)
-    const int nseg = a.nseg;
-    const int rowseg = tile / iblocks;
-    const int jrel = rowseg / nseg, seg = rowseg - jrel * nseg;
-    const int na = a.j1 - a.j0;
-    if (jrel >= na + (a.jb1 - a.jb0)) return;                // padding tiles
-    const int j = jrel < na ? a.j0 + jrel : a.jb0 + (jrel - na);
-    const int i = (tile - rowseg * iblocks) * kUpdThreads + threadIdx.x;
-    if (i >= W) return;
-    const int iw = i == 0 ? W - 1 : i - 1, ie = i + 1 == W ? 0 : i + 1;
-    const int jg = wrapi(a.row0 + j, a.Hg);
-    const T inv_dxj = a.inv_dxj[jg], inv_dxh = a.inv_dxh[jg], inv_dy = a.inv_dy, dt = a.dt;
-    const long rc = ix.r3(j), rn = ix.r3(j - 1), rs = ix.r3(j + 1);
-    // surface pressure of the stage state on rows j-1 .. j+2 (level independent)
-    const T *spr = a.sp;
-    const long p_n = ix.r2(j - 1), p_c = ix.r2(j), p_s = ix.r2(j + 1), p_ss = ix.r2(j + 2);
-    const T sp_c = spr[p_c + i], sp_e = spr[p_c + ie];
-    const T sp_s = spr[p_s + i], sp_se = spr[p_s + ie], sp_ss = spr[p_ss + i];
-    const T sp_n = spr[p_n + i], sp_ne = spr[p_n + ie];
-    const T jph_c = (sp_c + sp_s) * T(0.5), jph_ce = (sp_e + sp_se) * T(0.5);     // jph(sp) at (j,i),(j,i+1)
-    const T jph_n = (sp_n + sp_c) * T(0.5), jph_ne = (sp_ne + sp_e) * T(0.5);     // at (j-1,i),(j-1,i+1)
-    const T jph_s = (sp_s + sp_ss) * T(0.5);                                   // at (j+1,i)
-    const T pb_c = a.p[p_c + i], pb_e = a.p[p_c + ie], pb_s = a.p[p_s + i];
-    const T iph_pb = (pb_c + pb_e) * T(0.5), jph_pb = (pb_c + pb_s) * T(0.5);
-    const T pn_c = a.pn[p_c + i], pn_e = a.pn[p_c + ie], pn_s = a.pn[p_s + i];
-    const T inv_pnu = rcp((pn_c + pn_e) * T(0.5)), inv_pnv = rcp((pn_c + pn_s) * T(0.5)), inv_pn = rcp(pn_c);
-    const bool pole_edge = jg == a.Hg - 1;
-    const bool coriolis = a.cor_u != nullptr;
-    const bool same = a.u == a.su;
-    const T cp_u = coriolis ? a.cor_u[jg] : T(0.0), cp_v = coriolis ? a.cor_v[jg] : T(0.0);
-    if (seg == 0) a.op[(long)j * W + i] = pn_c;
-
-    // The levels are marched from the top down, because sigma-dot is the top-down running sum of
-    // conv (dynamics.py:42: cumsum(conv[::-1])[::-1] - pit sigb, sd[0] = 0): it is rebuilt here,
-    // for this column and its east and south neighbours (iph(sd), jph(sd)), from the mass fluxes
-    // the momentum advection loads anyway, instead of being read back from HBM.
-    // Vertical window: level k+1 (p), k (c), k-1 (m).  kp()/km() wrap (coordinates_3d.py:55-60):
-    // level L is 0 and level -1 is L-1; both only ever meet sd[0] = T(0.)
-    // This workgroup marches levels [k_lo, k_hi) of its columns (the whole column if nseg == 1).
-    const T inv_dxj_s = a.inv_dxj[wrapi(a.row0 + j + 1, a.Hg)];
-    const T pit_c = a.pit[p_c + i], pit_e = a.pit[p_c + ie], pit_s = a.pit[p_s + i];
-    const int k_lo = seg_lo(seg, nseg, L), k_hi = seg_lo(seg + 1, nseg, L);
-    if (k_hi <= k_lo) return;
-    const long top = (long)(L - 1) * W;
-    const long kp0 = k_hi == L ? 0 : (long)k_hi * W;            // level k_hi; level L wraps to 0
-    const long kc0 = (long)(k_hi - 1) * W;
-    T su_p = a.su[rc + kp0 + i], sv_p = a.sv[rc + kp0 + i], st_p = a.st[rc + kp0 + i], sq_p = a.sq[rc + kp0 + i];
-    T su_c = a.su[rc + kc0 + i], sv_c = a.sv[rc + kc0 + i], st_c = a.st[rc + kc0 + i], sq_c = a.sq[rc + kc0 + i];
-    // running sums of conv from the top and sd at level k_hi: zero above the top level, else from
-    // the partial sums pe_pit_kernel left at this segment boundary
-    T rc_c = T(0.0), rc_e = T(0.0), rc_s = T(0.0);
-    T sd_cp = T(0.0), sd_ep = T(0.0), sd_sp = T(0.0);
-    if (k_hi < L) {
-        const T *part = a.part + (long)seg * a.part_stride;
-        const T sgb_hi = a.sigb[k_hi];
-        rc_c = part[p_c + i]; rc_e = part[p_c + ie]; rc_s = part[p_s + i];
-        sd_cp = sd_of(rc_c, pit_c, sgb_hi);
-        sd_ep = sd_of(rc_e, pit_e, sgb_hi);
-        sd_sp = sd_of(rc_s, pit_s, sgb_hi);
-    }
-    // rho and phi of this column and its south neighbour are rebuilt per level (rho_of / phi_up):
-    // an odd level k takes the anchor phi[k-1] that pe_geopot_kernel stored and steps up from it,
-    // and leaves the level k-1 values it needed (anchor, exner factors, the south theta) for the
-    // next, even, iteration -- two exner evaluations per level and column on average
-    const T ptop = a.ptop;
-    bool have_lo = false;
-    T lo_ex_c = T(0.0), lo_ex_s = T(0.0), lo_phi_c = T(0.0), lo_phi_s = T(0.0), lo_st_s = T(0.0);
-    for (int k = k_hi - 1; k >= k_lo; --k) {
-        const long kc = (long)k * W;
-        T su_m, sv_m, st_m, sq_m;
-        if (k > 0) {
-            const long kmo = kc - W;
-            su_m = a.su[rc + kmo + i]; sv_m = a.sv[rc + kmo + i]; st_m = a.st[rc + kmo + i]; sq_m = a.sq[rc + kmo + i];
-        } else {
-            su_m = a.su[rc + top + i]; sv_m = a.sv[rc + top + i]; st_m = a.st[rc + top + i]; sq_m = a.sq[rc + top + i];
-        }
-        // stage winds, horizontal neighbours
-        const T su_w = a.su[rc + kc + iw], su_e = a.su[rc + kc + ie];
-        const T su_n = a.su[rn + kc + i], su_s = a.su[rs + kc + i];
-        const T sv_w = a.sv[rc + kc + iw], sv_e = a.sv[rc + kc + ie];
-        const T sv_n = a.sv[rn + kc + i], sv_ne = a.sv[rn + kc + ie], sv_s = a.sv[rs + kc + i];
-        // mass fluxes: spu filtered (K1); spv = sv * jph(sp), dynamics.py:20-22
-        const T spu_c = a.spu[rc + kc + i], spu_w = a.spu[rc + kc + iw], spu_e = a.spu[rc + kc + ie];
-        const T spu_s = a.spu[rs + kc + i], spu_sw = a.spu[rs + kc + iw];
-        const T spv_c = sv_c * jph_c, spv_e = sv_e * jph_ce;
-        const T spv_n = sv_n * jph_n, spv_ne = sv_ne * jph_ne;
-        const T spv_s = sv_s * jph_s;
-        // ---- aflux, dynamics.py:35-46, at (j,i), (j,i+1), (j+1,i)
-        const T dsg = a.dsig[k], sgb = a.sigb[k];
-        T sd_c = T(0.0), sd_e = T(0.0), sd_s = T(0.0);           // sd[0] = 0, dynamics.py:44
-        if (k > 0) {
-            rc_c = conv_acc(rc_c, spu_c, spu_w, inv_dxj, sv_c, jph_c, sv_n, jph_n, inv_dy, dsg);
-            rc_e = conv_acc(rc_e, spu_e, spu_c, inv_dxj, sv_e, jph_ce, sv_ne, jph_ne, inv_dy, dsg);
-            rc_s = conv_acc(rc_s, spu_s, spu_sw, inv_dxj_s, sv_s, jph_s, sv_c, jph_c, inv_dy, dsg);
-            sd_c = sd_of(rc_c, pit_c, sgb);
-            sd_e = sd_of(rc_e, pit_e, sgb);
-            sd_s = sd_of(rc_s, pit_s, sgb);
-        }
-        // ---- advec_m_pu, dynamics.py:55-108
-        const T puum = ((su_c + su_w) * T(0.5)) * ((spu_c + spu_w) * T(0.5));
-        const T puup = ((su_e + su_c) * T(0.5)) * ((spu_e + spu_c) * T(0.5));
-        const T puvp = ((spv_c + spv_e) * T(0.5)) * ((su_c + su_s) * T(0.5));
-        const T puvm = ((spv_n + spv_ne) * T(0.5)) * ((su_n + su_c) * T(0.5));
-        const T pvvm = ((sv_c + sv_n) * T(0.5)) * ((spv_c + spv_n) * T(0.5));
-        const T pvvp = ((sv_s + sv_c) * T(0.5)) * ((spv_s + spv_c) * T(0.5));
-        const T pvup = ((sv_c + sv_e) * T(0.5)) * ((spu_c + spu_s) * T(0.5));
-        const T pvum = ((sv_w + sv_c) * T(0.5)) * ((spu_w + spu_sw) * T(0.5));
-        T cor_u = T(0.0), cor_v = T(0.0);                         // the reference adds a literal 0
-        if (coriolis) {                                          // dynamics.py:83-92
-            const T pu_at_pv = (((spu_c + spu_s) * T(0.5)) + ((spu_w + spu_sw) * T(0.5))) * T(0.5);    // imh(jph(pu))
-            const T pv_at_pu = (((spv_c + spv_n) * T(0.5)) + ((spv_e + spv_ne) * T(0.5))) * T(0.5);    // iph(jmh(pv))
-            cor_u = cp_u * -pv_at_pu;
-            cor_v = cp_v * pu_at_pv;
-        }
-        const T dut = (puum - puup) * inv_dxj + (puvm - puvp) * inv_dy + cor_u;
-        const T dvt = (pvvm - pvvp) * inv_dy + (pvum - pvup) * inv_dxh + cor_v;
-        // ---- pgf v-part, dynamics.py:160,167-169 (the u-part went through K3)
-        const T sg = a.sig[k];
-        T ex_c, ex_s, phi_c, phi_s, st_s;
-        if (have_lo) {
-            ex_c = lo_ex_c; ex_s = lo_ex_s; phi_c = lo_phi_c; phi_s = lo_phi_s; st_s = lo_st_s;
-        } else {
-            ex_c = exner(sp_c * sg + ptop, tab);
-            ex_s = exner(sp_s * sg + ptop, tab);
-            st_s = a.st[rs + kc + i];
-            phi_c = phi_s = T(0.0);
-            if ((k & 1) == 0) { phi_c = a.phi[rc + kc + i]; phi_s = a.phi[rs + kc + i]; }
-        }
-        have_lo = (k & 1) != 0;
-        if (have_lo) {                                            // k odd: k - 1 >= 0 is an anchor level
-            const T sg_lo = a.sig[k - 1];
-            lo_ex_c = exner(sp_c * sg_lo + ptop, tab);
-            lo_ex_s = exner(sp_s * sg_lo + ptop, tab);
-            lo_st_s = a.st[rs + kc - W + i];
-            lo_phi_c = a.phi[rc + kc - W + i];
-            lo_phi_s = a.phi[rs + kc - W + i];
-            phi_c = phi_up(lo_phi_c, st_m, st_c, lo_ex_c, ex_c);
-            phi_s = phi_up(lo_phi_s, lo_st_s, st_s, lo_ex_s, ex_s);
-        }
-        const T rho_c = rho_of(sp_c * sg + ptop, st_c, ex_c), rho_s = rho_of(sp_s * sg + ptop, st_s, ex_s);
-        const T phiv = jph_c * ((phi_s - phi_c) * inv_dy);
-        const T pgv = ((sg * sp_c + sg * sp_s) * T(0.5)) * rcp((rho_c + rho_s) * T(0.5)) * ((sp_s - sp_c) * inv_dy);
-        // ---- vertical advection, dynamics.py:49-52 with iph(sd), jph(sd), sd
-        const T inv_ds = a.inv_dsig[k];
-        const T sdi = (sd_c + sd_e) * T(0.5), sdi_p = (sd_cp + sd_ep) * T(0.5);
-        const T sdj = (sd_c + sd_s) * T(0.5), sdj_p = (sd_cp + sd_sp) * T(0.5);
-        const T dus = -((((su_c + su_m) * T(0.5)) * sdi - ((su_p + su_c) * T(0.5)) * sdi_p) * inv_ds);
-        const T dvs = -((((sv_c + sv_m) * T(0.5)) * sdj - ((sv_p + sv_c) * T(0.5)) * sdj_p) * inv_ds);
-        const T dts = -((((st_c + st_m) * T(0.5)) * sd_c - ((st_p + st_c) * T(0.5)) * sd_cp) * inv_ds);
-        const T dqs = -((((sq_c + sq_m) * T(0.5)) * sd_c - ((sq_p + sq_c) * T(0.5)) * sd_cp) * inv_ds);
-        // ---- momentum update, dynamics.py:186-212
-        // predictor: the stage state IS the base state, its values are in the window already
-        const T pu = (same ? su_c : a.u[rc + kc + i]) * iph_pb;
-        const T pv = (same ? sv_c : a.v[rc + kc + i]) * jph_pb;
-        const T pgfu = a.pgfu[rc + kc + i];
-        const T pu_n = pu - (dut + dus + pgfu) * dt;
-        const T pv_n = pv - (dvt + dvs + phiv + pgv) * dt;
-        T u_n = pu_n * inv_pnu;
-        T v_n = pv_n * inv_pnv;
-        if (pole_edge) v_n *= T(0.0);                               // v_n[:, -1, :] *= 0, dynamics.py:222
-        // ---- advec_t for t and q, dynamics.py:174-181,214-219
-        const T st_e = a.st[rc + kc + ie], st_w = a.st[rc + kc + iw];
-        const T st_n = a.st[rn + kc + i];
-        const T sq_e = a.sq[rc + kc + ie], sq_w = a.sq[rc + kc + iw];
-        const T sq_s = a.sq[rs + kc + i], sq_n = a.sq[rn + kc + i];
-        const T adt = (spu_c * ((st_c + st_e) * T(0.5)) - spu_w * ((st_w + st_c) * T(0.5))) * inv_dxj +
-                           (spv_c * ((st_c + st_s) * T(0.5)) - spv_n * ((st_n + st_c) * T(0.5))) * inv_dy;
-        const T adq = (spu_c * ((sq_c + sq_e) * T(0.5)) - spu_w * ((sq_w + sq_c) * T(0.5))) * inv_dxj +
-                           (spv_c * ((sq_c + sq_s) * T(0.5)) - spv_n * ((sq_n + sq_c) * T(0.5))) * inv_dy;
-        const T t_n = ((same ? st_c : a.t[rc + kc + i]) * pb_c - (adt + dts) * dt) * inv_pn;
-        const T q_n = ((same ? sq_c : a.q[rc + kc + i]) * pb_c - (adq + dqs) * dt) * inv_pn;
-        const long o = (long)j * L * W + kc + i;                 // interior rows: no wrap needed
-        a.ou[o] = u_n;
-        a.ov[o] = v_n;
-        a.ot[o] = t_n;
-        a.oq[o] = q_n;
-        // rotate the vertical window downwards
-        su_p = su_c; sv_p = sv_c; st_p = st_c; sq_p = sq_c;
-        su_c = su_m; sv_c = sv_m; st_c = st_m; sq_c = sq_m;
-        sd_cp = sd_c; sd_ep = sd_e; sd_sp = sd_s;
-    }
-}
-
-// ---------------------------------------------------------------- K4, row-group form
+// The levels are marched from the top down, because sigma-dot is the top-down running sum of conv
+// (dynamics.py:42: cumsum(conv[::-1])[::-1] - pit sigb, sd[0] = 0): it is rebuilt here from the mass
+// fluxes the momentum advection loads anyway, instead of being read back from HBM.  kp()/km() wrap
+// (coordinates_3d.py:55-60): level L is 0 and level -1 is L-1; both only ever meet sd[0] = 0.
 // A workgroup is R compute waves = R consecutive rows x 62 columns (lanes 1..62; lanes 0 and 63
 // carry the halo columns i-1 / i+1 and are not stored) plus ONE loader wave, marching the levels
 // top-down in lockstep.  Everything the march reads from global memory goes through LDS tiles, one
@@ -566,8 +370,6 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
     }
 }
 
-template <typename T>
-FilterKernel<T> update_kernel_for() { return pe_update_kernel<T>; }
 template <typename T>
 FilterKernel<T> update_rows_kernel_for(int rows_per_group, bool same) {
     if (rows_per_group == 7) return same ? pe_update_rows_kernel<T, 7, true> : pe_update_rows_kernel<T, 7, false>;

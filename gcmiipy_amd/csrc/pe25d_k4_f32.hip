@@ -3,6 +3,5 @@
 #include "pe25d_k4.h"
 
 namespace gcm {
-template FilterKernel<float> update_kernel_for<float>();
 template FilterKernel<float> update_rows_kernel_for<float>(int, bool);
 }  // namespace gcm

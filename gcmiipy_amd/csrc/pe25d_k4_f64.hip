@@ -3,6 +3,5 @@
 #include "pe25d_k4.h"
 
 namespace gcm {
-template FilterKernel<double> update_kernel_for<double>();
 template FilterKernel<double> update_rows_kernel_for<double>(int, bool);
 }  // namespace gcm

@@ -471,7 +471,7 @@ struct Pe25d {
     int cur_i = 0;
     bool star_valid = false;
     int nseg = 1;                               // level segments of K4, chosen from the band's size
-    int upd_rows = 7;                           // rows per workgroup of the row-group K4 (0: one-wave form)
+    int upd_rows = 7;                           // rows per workgroup of K4 (3 or 7)
     int cus = 256;
     int last_stage_set = -1;                    // state set the last half step took its stage state from (gcm_get_intermediate)
     int ghost_ready = -1;                       // state set whose ghost rows' column sums and anchors are queued already (pe25d_prep_ghost_rows)
@@ -769,17 +769,13 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
         bool forced = false;
         if (const char *e = getenv("GCM_PE_LEVEL_SEGMENTS")) { want = atoi(e); forced = true; }
         if (const char *e = getenv("GCM_PE_PIT2D")) m->pit2d = atoi(e) != 0;      // 0: pit from the 3-D fields (pe_pit_kernel)
-        if (const char *e = getenv("GCM_PE_UPDATE_ROWS")) {      // 0: the one-wave update kernel; 3, 7: rows per group
-            const int v = atoi(e);
-            m->upd_rows = (v == 0 || v == 3 || v == 7) ? v : 7;
-        }
+        if (const char *e = getenv("GCM_PE_UPDATE_ROWS")) m->upd_rows = atoi(e) == 3 ? 3 : 7;      // rows per workgroup
         const int cap = std::min(kMaxSeg, std::max(1, L / 4));
         m->nseg = (int)std::max(1L, std::min((long)cap, want));
-        // the row-group K4 fills the chip with whole columns (a 90-row band: 2 % slower than in two
-        // segments) and then leaves the column sums pit needs: segments only on request, or for the
-        // one-wave kernel
-        if (m->upd_rows > 0 && !forced) m->nseg = 1;
-        if (!m->wrap && m->upd_rows > 0 && m->nseg == 1 && m->pit2d && m->H > 2 * kGhost) {
+        // K4 fills the chip with whole columns (a 90-row band: 2 % slower than in two segments) and then
+        // leaves the column sums pit needs: segments only on request
+        if (!forced) m->nseg = 1;
+        if (!m->wrap && m->nseg == 1 && m->pit2d && m->H > 2 * kGhost) {
             m->nseg_edge = std::min(kMaxSeg, std::max(1, L / 6));
             if (const char *e = getenv("GCM_PE_EDGE_SEGMENTS")) m->nseg_edge = std::max(1, std::min(kMaxSeg, atoi(e)));
             if (L / m->nseg_edge < 2) m->nseg_edge = 1;
@@ -978,7 +974,7 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
     const int fft_threads = m->cplan.ok ? m->cplan.threads : kFftThreads;
     const int pairs = (L + 1) / 2;
     // pit from the 2-D column sums (pe_pit2d_kernel) where K4 marches whole columns and can leave them
-    const bool p2 = m->pit2d && a.nseg == 1 && m->upd_rows > 0;
+    const bool p2 = m->pit2d && a.nseg == 1;
     if (p2) {
         a.ocs_u = bufs<T>(m).cs[out_set][0];
         a.ocs_v = bufs<T>(m).cs[out_set][1];
@@ -1078,19 +1074,14 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         a.j1 = std::max(r0, r1);
         a.jb0 = rb0;
         a.jb1 = std::max(rb0, rb1);
-        if (m->upd_rows > 0) {
-            const int Rg = m->upd_rows;
-            const long groups = (std::max(0, r1 - r0) + Rg - 1) / Rg + (std::max(0, rb1 - rb0) + Rg - 1) / Rg;
-            // 8 XCDs x (row group, segment) pairs per XCD x column tiles (see the kernel's index map)
-            const long rs_per_xcd = (groups * a.nseg + 7) / 8;
-            const dim3 gg((unsigned)(8 * rs_per_xcd * ((W + kUpdCols - 1) / kUpdCols)));
-            const size_t lds = upd_lds_bytes<T>(Rg, L);
-            const bool same = a.u == a.su;
-            hipLaunchKernelGGL(update_rows_kernel_for<T>(Rg, same), gg, dim3(64 * (Rg + 1)), lds, st, a);
-            return;
-        }
-        const long tiles = (long)((W + kUpdThreads - 1) / kUpdThreads) * rows * a.nseg;
-        hipLaunchKernelGGL(update_kernel_for<T>(), dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(kUpdThreads), 0, st, a);
+        const int Rg = m->upd_rows;
+        const long groups = (std::max(0, r1 - r0) + Rg - 1) / Rg + (std::max(0, rb1 - rb0) + Rg - 1) / Rg;
+        // 8 XCDs x (row group, segment) pairs per XCD x column tiles (see the kernel's index map)
+        const long rs_per_xcd = (groups * a.nseg + 7) / 8;
+        const dim3 gg((unsigned)(8 * rs_per_xcd * ((W + kUpdCols - 1) / kUpdCols)));
+        const size_t lds = upd_lds_bytes<T>(Rg, L);
+        const bool same = a.u == a.su;
+        hipLaunchKernelGGL(update_rows_kernel_for<T>(Rg, same), gg, dim3(64 * (Rg + 1)), lds, st, a);
     };
     m->cs_valid[out_set] = p2;                   // (modes 1 + 2 together cover the rows)
     const bool split = mode != 0 && (j1 - j0) > 2 * kGhost;
@@ -1150,7 +1141,7 @@ void pe25d_prep_ghost_rows(Pe25d *m) {
     if (m->wrap || !m->aux) return;
     int set = m->star_valid ? 2 : m->cur_i;                      // the set the unpack has just filled (halo_t)
     if (m->pack_set >= 0 && m->pack_set != 2) set = m->pack_set;
-    const bool p2 = m->pit2d && m->nseg == 1 && m->upd_rows > 0;
+    const bool p2 = m->pit2d && m->nseg == 1;
     if (p2 && !m->cs_valid[set]) return;                         // (a fresh state: the stage does all rows itself)
     if (m->f32) {
         PeArgsT<float> a = make_args<float>(m, set, set, 0.0);
