@@ -54,11 +54,13 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
     const int W = a.W, L = a.L;
     const int ncol = (W + kUpdCols - 1) / kUpdCols;
     // Workgroup = ((row group, level segment), column tile); groups come from [j0, j1) then [jb0, jb1).
-    // Each XCD (workgroups b, b+8, ... share one) takes a contiguous run of (group, segment) pairs and
-    // walks it with the COLUMN TILE fastest: the workgroups resident on an XCD at one time are the 24 column
-    // tiles of one or two row groups, marching in step, so that a level's rows leave HBM as whole 11.5 KB
-    // rows within a short time instead of as 512-byte pieces spread over the launch (round 3: -4.5 % on
-    // this kernel against the group-fastest walk of round 2, which traded that for L2 hits on the halo rows).
+    // Each XCD (workgroups b, b+8, ... share one) takes every eighth (group, segment) pair and walks its
+    // share with the COLUMN TILE fastest: the workgroups resident on an XCD at one time are the 24 column
+    // tiles of one or two row groups, marching in step, and the eight XCDs work on eight ADJACENT groups --
+    // a level's rows leave HBM as whole 11.5 KB rows within a short time and the chip's traffic stays in one
+    // compact region of each field, instead of 512-byte pieces from eight distant regions (round 3: -5.5 %
+    // on this kernel against the walk of round 2 -- contiguous groups per XCD, group fastest -- which bought
+    // L2 hits on the halo rows with exactly that scatter).
     const int nseg = a.nseg;
     const int na = a.j1 - a.j0, nb = a.jb1 - a.jb0;
     const int ga = (na + R - 1) / R, gb = (nb + R - 1) / R;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
     const int l = blockIdx.x / 8;
     const int rsl = l / ncol;
     const int ct = l - rsl * ncol;
-    const int rowseg = (blockIdx.x % 8) * rs_per_xcd + rsl;
+    const int rowseg = rsl * 8 + (blockIdx.x % 8);
     const int grp = rowseg / nseg, seg = rowseg - grp * nseg;
     if (grp >= ga + gb) return;                                  // padding workgroups (uniform)
     const int jg = grp < ga ? a.j0 + grp * R : a.jb0 + (grp - ga) * R;
