@@ -1,0 +1,11 @@
+for lib in default /root/repo/exp_libs/libgcm_kji.so default /root/repo/exp_libs/libgcm_kji.so; do
+  if [ $lib = default ]; then unset GCMCORE_LIB; else export GCMCORE_LIB=$lib; fi
+  rm -rf /root/repo/gpurun_out/ab_k; mkdir -p /root/repo/gpurun_out/ab_k; cd /tmp; export TMPDIR=/tmp
+  GCM_PE_SINGLE_STREAM=1 GCM_BENCH_MIN_TIMED_S=0.1 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/ab_k -- python3 /root/repo/bench.py --no-cpu --only --workload c4 --steps 8 --warmup 2 > /root/repo/gpurun_out/ab_k/out.txt 2>&1
+  echo "== $lib"; tail -1 /root/repo/gpurun_out/ab_k/out.txt | cut -c1-200; python3 - <<PY
+import csv,glob
+f=glob.glob("/root/repo/gpurun_out/ab_k/*/*_kernel_stats.csv")[0]
+for r in csv.DictReader(open(f)):
+    if "gcm::pe_" in r["Name"] and "to_" not in r["Name"]: print("%-60s %8.1f us x %s" % (r["Name"][:60], float(r["AverageNs"])/1e3, r["Calls"]))
+PY
+done
