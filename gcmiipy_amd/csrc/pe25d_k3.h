@@ -28,7 +28,6 @@ __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
     using V = typename Vec2<T>::type;
     extern __shared__ unsigned char lds_raw[];
     __shared__ double tab[kExnerTabDoubles];
-    __shared__ PgfCol<T> edge[kMaxEdgeCols];
     V *x = (V *)lds_raw;
     for (int n = threadIdx.x; n < kExnerTabDoubles; n += blockDim.x) tab[n] = a.exner_tab[n];
     const Idx ix{a.W, a.H, a.L, a.wrap};
@@ -53,12 +52,10 @@ __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
     const T sg0 = a.sig[k0], sg1 = two ? a.sig[k1] : sg0;
     const T ptop = a.ptop;
     T *out = a.pgfu + o0;
-    const int wpad = (W + 63) / 64 * 64;
     __syncthreads();
     // what a column needs from memory, and what is made of it
     struct Raw { T pc, pe, t0, t1, ph; };
-    const auto request = [=](int i_raw) {
-        const int i = i_raw < W ? i_raw : W - 1;
+    const auto request = [=](int i) {
         const int ie = i + 1 == W ? 0 : i + 1;
         return Raw{sp[i], sp[ie], st0[i], st1[i], phi0[i]};
     };
@@ -72,19 +69,19 @@ __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
         c.phi1 = phi_up(c.phi0, r.t0, r.t1, ex0, ex1);
         return c;
     };
-    for (int e = threadIdx.x; e * 64 < W; e += blockDim.x) edge[e] = column_of(request(e * 64));
-    __syncthreads();
-    // every lane of a wave goes through the loop body (DPP reads its neighbour lane): columns past
-    // the end are clamped and not stored
+    // A wave covers 63 columns; its lane 63 computes the column after them only to hand it to lane 62 (the east
+    // neighbour of every column comes from the next lane, DPP), so consecutive waves overlap by one column and
+    // nothing has to cross a wave.  (Rounds 1-2 filled a table of the columns that are multiples of 64 first:
+    // one more memory latency and a barrier at the head of every workgroup.)  The row's last column takes
+    // column 0 as its east neighbour the same way: column indices wrap.
     const int lane = threadIdx.x & 63;
-    const auto value = [&](int i_raw, const Raw &r) {
-        const int i = i_raw < W ? i_raw : W - 1;
-        const int ie = i + 1 == W ? 0 : i + 1;
+    const int wv = threadIdx.x >> 6, nwav = blockDim.x >> 6;
+    const int nchunks = (W + 62) / 63;
+    const auto value = [&](const Raw &r) {
         const PgfCol<T> c = column_of(r);
         PgfCol<T> e;
         e.rho0 = from_east(c.rho0); e.rho1 = from_east(c.rho1);
         e.phi0 = from_east(c.phi0); e.phi1 = from_east(c.phi1);
-        if (lane == 63 || ie == 0) e = edge[ie >> 6];
         const T pc = r.pc, pe = r.pe;
         const T iphp = (pc + pe) * T(0.5);
         const T gradp = (pe - pc) * inv_dxj;
@@ -95,17 +92,18 @@ __global__ __launch_bounds__(512) void pe_pgf_filter_kernel(PeArgsT<T> a) {
         return mkv<V>(pgu0 + phiu0, two ? pgu1 + phiu1 : T(0.0));
     };
     // the columns of a thread are requested kPgfBatch at a time (one memory latency per batch instead
-    // of one per column), then worked off
+    // of one per column), then worked off; every lane of a wave goes through the loop body
     const auto sweep = [&](const auto &sink) {
-        for (int base = threadIdx.x; base < wpad; base += kPgfBatch * (int)blockDim.x) {
+        for (int ch0 = wv; ch0 < nchunks; ch0 += kPgfBatch * nwav) {
             Raw r[kPgfBatch];
 #pragma unroll
-            for (int m = 0; m < kPgfBatch; ++m) r[m] = request(min(base + m * (int)blockDim.x, wpad - 1));
+            for (int m = 0; m < kPgfBatch; ++m) r[m] = request((min(ch0 + m * nwav, nchunks - 1) * 63 + lane) % W);
 #pragma unroll
             for (int m = 0; m < kPgfBatch; ++m) {
-                const int i = base + m * (int)blockDim.x;
-                const V v = value(min(i, wpad - 1), r[m]);
-                if (i < W) sink(i, v);
+                const int ch = ch0 + m * nwav;
+                const int i = ch * 63 + lane;
+                const V v = value(r[m]);
+                if (ch < nchunks && lane < 63 && i < W) sink(i, v);
             }
         }
     };
