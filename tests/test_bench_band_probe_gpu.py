@@ -62,3 +62,23 @@ def test_run_workload_pe25d_band_path(monkeypatch):
         res = bench.run_workload(cx, "c4", 4, 2, want_kernel=False)
     assert res["n_gpus"] == 8 and res["ms_per_step"] > 0 and np.isfinite(res["value"])
     assert res["band_overlap_probe_ms_per_step"] is None
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` as the driver types it, with no launcher and no WORLD_SIZE in the
+    environment: the parent starts the two ranks itself (a child torch.distributed.run job; gloo here, since
+    RCCL refuses two ranks on one device), rank 0 prints ONE JSON line with n_gpus == 2, the exit code is the
+    job's"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GCM_BENCH_BACKEND="gloo", GCM_BENCH_SETTLE_S="0.01", GCM_BENCH_MIN_TIMED_S="0.02")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4",
+                        "--only", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert "exchange" in d and "exchange_fallback" in d
+    assert d["diagnostics"]["host_queue_ms_per_step_idle_device"] > 0
