@@ -1,4 +1,7 @@
-for lib in default /root/repo/exp_libs/libgcm_nocs.so default /root/repo/exp_libs/libgcm_nocs.so; do
+#!/bin/bash
+# per-kernel durations (single stream) of bench.py --workload c4 under rocprofv3, for several builds on one box:
+# bash tools/tools_ab_kernels.sh default /path/to/alt1.so ...
+for lib in "$@"; do
   if [ $lib = default ]; then unset GCMCORE_LIB; else export GCMCORE_LIB=$lib; fi
   rm -rf /root/repo/gpurun_out/ab_k; mkdir -p /root/repo/gpurun_out/ab_k; cd /tmp; export TMPDIR=/tmp
   GCM_PE_SINGLE_STREAM=1 GCM_BENCH_MIN_TIMED_S=0.1 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/ab_k -- python3 /root/repo/bench.py --no-cpu --only --workload c4 --steps 8 --warmup 2 > /dev/null 2>&1
