@@ -350,11 +350,15 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
             # behind one long spin kernel (torch.cuda._sleep, ~40 ms).  "host_queue_ms_per_step" above it is
             # taken on a busy device and also counts the time the queue holds the host back.
             nq = max(k, 4) // k * k
-            torch.cuda.synchronize()
-            torch.cuda._sleep(int(40e-3 * 2.0e9))
-            tq = time.perf_counter()
-            lb.run(nq, dt)
-            host_idle = (time.perf_counter() - tq) * 1e3 / nq
+            host_idle = None
+            try:
+                torch.cuda.synchronize()
+                torch.cuda._sleep(int(40e-3 * 2.0e9))
+                tq = time.perf_counter()
+                lb.run(nq, dt)
+                host_idle = (time.perf_counter() - tq) * 1e3 / nq
+            except AttributeError:              # (a torch without the spin kernel: the figure is simply absent)
+                pass
             torch.cuda.synchronize()
             res["diagnostics"] = {"host_queue_ms_per_step": t_queued / steps * 1e3,
                                   "host_queue_ms_per_step_idle_device": host_idle,
