@@ -26,6 +26,7 @@ struct SuperPlan {
     unsigned mask;                 // pass_bit() of every pass
     int r1[kMaxSuper], r2[kMaxSuper];
     unsigned magic[kMaxSuper];     // ceil(2^32 / Ns) of the pass
+    unsigned imagic[kMaxSuper];    // the same for the inverse transform, whose passes run in REVERSED radix order
 };
 
 template <typename T> struct Vec2;
@@ -330,8 +331,70 @@ __device__ __forceinline__ void pass_dispatch(int r1, int r2, const Src &src, co
 #undef GCM_PASS
 }
 
+// The LAST forward pass, the filter multiplier and the FIRST inverse pass as one register-resident step.
+// The inverse transform takes the plan's radices in reversed order, so its first pass (Ns = 1, no pass
+// twiddles) has the radix R of the last forward pass and reads x[b + m N/R], m = 0..R-1 -- exactly the
+// elements X[b + q N/R] thread b holds when its last forward butterfly is done (Stockham leaves natural
+// order).  The spectrum therefore never goes to LDS: one round trip and one barrier pair less per
+// filtered row than forward passes, multiply-on-read, inverse passes.  mult(n) = S[n folded] / N.
+// Thread b writes x[b R + q] (the Ns = 1 output positions of the inverse pass).
+template <int R1, int R2, typename V, typename Src, typename Dst, typename Mult>
+__device__ __forceinline__ void merged_pass(const Src &src, const Dst &dst, bool fence, bool twiddle, const Mult &mult,
+                                            const V *tw, int N, const V *wpre = nullptr, int tid = -1) {
+    constexpr int R = R1 * R2;
+    const int nb = N / R;
+    const int b = tid >= 0 ? tid : (int)threadIdx.x;
+    const bool act = b < nb;
+    V v[R];
+    if (act) {
+#pragma unroll
+        for (int m = 0; m < R; ++m) v[m] = src(b + m * nb, m);
+        if (twiddle) {                                // not the only pass: Ns = N / R = nb, k = b, t1 = b
+            V wp[R];
+            wp[1] = wpre ? *wpre : tw[b];
+#pragma unroll
+            for (int m = 2; m < R; ++m) wp[m] = (m % 2 == 0) ? cmul(wp[m / 2], wp[m / 2]) : cmul(wp[m - 1], wp[1]);
+#pragma unroll
+            for (int m = 1; m < R; ++m) v[m] = cmul(v[m], wp[m]);
+        }
+        dft_composite<R1, R2, false>(v, tw, nb);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const Sc<V> sc = mult(b + q * nb);
+            v[q].x *= sc;
+            v[q].y *= sc;
+        }
+        dft_composite<R1, R2, true>(v, tw, nb);
+    }
+    if (fence) __syncthreads();
+    if (act) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) dst(b * R + q, v[q]);
+    }
+    __syncthreads();
+}
+
+template <int MAXR, unsigned MASK, typename V, typename Src, typename Dst, typename Mult>
+__device__ __forceinline__ void merged_dispatch(int r1, int r2, const Src &src, const Dst &dst, bool fence, bool twiddle,
+                                                const Mult &mult, const V *tw, int N, const V *wpre = nullptr, int tid = -1) {
+#define GCM_PASS(A, B)                                                                      \
+    case (A) * 8 + (B):                                                                     \
+        if constexpr ((A) * (B) <= MAXR && (MASK == 0 || (MASK & pass_bit(A, B)) != 0))     \
+            merged_pass<A, B>(src, dst, fence, twiddle, mult, tw, N, wpre, tid);            \
+        break;
+    switch (r1 * 8 + r2) {
+        GCM_PASS(2, 1) GCM_PASS(3, 1) GCM_PASS(4, 1) GCM_PASS(5, 1)
+        GCM_PASS(3, 2) GCM_PASS(4, 2) GCM_PASS(3, 3) GCM_PASS(5, 2) GCM_PASS(4, 3)
+        GCM_PASS(5, 3) GCM_PASS(4, 4) GCM_PASS(5, 4) GCM_PASS(5, 5)
+        default: break;
+    }
+#undef GCM_PASS
+}
+
 // Filter the two real rows that `load(i)` delivers as re/im: forward FFT, multiply by S[n]/N
 // (n folded, low_pass.py:61-72; numpy's irfft scales by 1/N), inverse FFT, `store(i, V)`.
+// Forward passes 0 .. np-2, the merged pass (last forward + multiplier + first inverse), inverse passes
+// 1 .. np-1 with the radices reversed: 2 np - 1 passes, 2 np - 2 LDS round trips.
 template <int MAXR, unsigned MASK, typename T, typename Load, typename Store>
 __device__ __forceinline__ void filter_rows_composite(typename Vec2<T>::type *x, const Load &load, const Store &store,
                                                       const typename Vec2<T>::type *tw, const SuperPlan &P, int N,
@@ -340,31 +403,28 @@ __device__ __forceinline__ void filter_rows_composite(typename Vec2<T>::type *x,
     const T inv_n = T(1.0) / (T)N;
     const auto lds_src = [x](int i, int) { return x[i]; };
     const auto lds_dst = [x](int i, V v) { x[i] = v; };
-    const auto lds_src_filtered = [x, S, N, inv_n](int i, int) {
-        const T s = S[i <= N / 2 ? i : N - i] * inv_n;
-        const V v = x[i];
-        return mkv<V>(v.x * s, v.y * s);
-    };
+    const auto mult = [S, N, inv_n](int n) { return S[n <= N / 2 ? n : N - n] * inv_n; };
+    const int np = P.npass;
+    if (np == 1) {
+        merged_dispatch<MAXR, MASK, V>(P.r1[0], P.r2[0], load, store, false, false, mult, tw, N);
+        return;
+    }
     // the first and the last pass of either direction are written out rather than selected inside
     // one loop: their global addresses would otherwise be hoisted out of it and pinned in registers
-    const int np = P.npass;
     int Ns = P.r1[0] * P.r2[0];
     pass_dispatch<MAXR, MASK, false>(P.r1[0], P.r2[0], load, lds_dst, load_reads_x, tw, N, 1, P.magic[0]);
-    for (int pass = 1; pass < np; ++pass) {
+    for (int pass = 1; pass < np - 1; ++pass) {
         pass_dispatch<MAXR, MASK, false>(P.r1[pass], P.r2[pass], lds_src, lds_dst, true, tw, N, Ns, P.magic[pass]);
         Ns *= P.r1[pass] * P.r2[pass];
     }
-    if (np == 1) {
-        pass_dispatch<MAXR, MASK, true>(P.r1[0], P.r2[0], lds_src_filtered, store, false, tw, N, 1, P.magic[0]);
-        return;
-    }
-    pass_dispatch<MAXR, MASK, true>(P.r1[0], P.r2[0], lds_src_filtered, lds_dst, true, tw, N, 1, P.magic[0]);
-    Ns = P.r1[0] * P.r2[0];
-    for (int pass = 1; pass < np - 1; ++pass) {
-        pass_dispatch<MAXR, MASK, true>(P.r1[pass], P.r2[pass], lds_src, lds_dst, true, tw, N, Ns, P.magic[pass]);
+    merged_dispatch<MAXR, MASK, V>(P.r1[np - 1], P.r2[np - 1], lds_src, lds_dst, true, true, mult, tw, N);
+    Ns = P.r1[np - 1] * P.r2[np - 1];
+    for (int q = 1; q < np - 1; ++q) {
+        const int pass = np - 1 - q;
+        pass_dispatch<MAXR, MASK, true>(P.r1[pass], P.r2[pass], lds_src, lds_dst, true, tw, N, Ns, P.imagic[q]);
         Ns *= P.r1[pass] * P.r2[pass];
     }
-    pass_dispatch<MAXR, MASK, true>(P.r1[np - 1], P.r2[np - 1], lds_src, store, false, tw, N, Ns, P.magic[np - 1]);
+    pass_dispatch<MAXR, MASK, true>(P.r1[0], P.r2[0], lds_src, store, false, tw, N, Ns, P.imagic[np - 1]);
 }
 
 // The same filter for a workgroup that loops over several row pairs of ONE latitude (the filter
@@ -372,69 +432,79 @@ __device__ __forceinline__ void filter_rows_composite(typename Vec2<T>::type *x,
 // fetch from tables is fetched once, before the loop, into FilterConsts, and the first forward pass
 // takes its inputs from registers (`first(i, m)`: the m-th input of this thread's butterfly, element
 // i = threadIdx.x + m N / R0), so that a caller can request the next pair's inputs while this pair is
-// transformed.  The multiplier row (already divided by N) is read from LDS.  Plans of up to four passes.
-template <typename T>
+// transformed.  The multiplier row (already divided by N) is read from LDS.  Plans of two to four passes.
+// Base twiddles (forward sign): w[0] = tw[b], shared by the merged pass (last forward, Ns = N / R) and the
+// last inverse pass (Ns = N / R0); w[p], p = 1 .. np-2: forward pass p; w[np-2+q], q = 1 .. np-2: inverse
+// pass q.  NW = 3 serves plans of up to three passes, 5 those of four.
+template <typename T, int NW = 5>
 struct FilterConsts {
-    typename Vec2<T>::type w[3];   // base twiddle of passes 1..3 (forward sign)
+    typename Vec2<T>::type w[NW];
     const T *s;                    // LDS: S[n] / N, n = 0 .. N/2 (the caller fills it)
 };
-template <typename T>
-__device__ __forceinline__ void filter_consts(FilterConsts<T> &c, const typename Vec2<T>::type *tw, const SuperPlan &P, int N) {
+template <typename T, int NW>
+__device__ __forceinline__ void filter_consts(FilterConsts<T, NW> &c, const typename Vec2<T>::type *tw, const SuperPlan &P, int N) {
     using V = typename Vec2<T>::type;
     const int b = threadIdx.x;
+    const int np = P.npass;
+#pragma unroll
+    for (int n = 0; n < NW; ++n) c.w[n] = mkv<V>(T(1.0), T(0.0));
+    c.w[0] = tw[min(b, N - 1)];
     int Ns = P.r1[0] * P.r2[0];
 #pragma unroll
-    for (int pass = 1; pass < 4; ++pass) {
-        c.w[pass - 1] = mkv<V>(T(1.0), T(0.0));
-        if (pass < P.npass) {
+    for (int pass = 1; pass < (NW + 1) / 2; ++pass) {            // forward passes 1 .. np-2
+        if (pass < np - 1) {
             const int R = P.r1[pass] * P.r2[pass], nb = N / R;
             const int bb = min(b, nb - 1);
             const int blk = (int)__umulhi((unsigned)bb, P.magic[pass]);
             const int k = bb - blk * Ns;
-            c.w[pass - 1] = tw[k * (nb / Ns)];
+            c.w[pass] = tw[k * (nb / Ns)];
+            Ns *= R;
+        }
+    }
+    Ns = P.r1[np - 1] * P.r2[np - 1];
+#pragma unroll
+    for (int q = 1; q < (NW + 1) / 2; ++q) {                     // inverse passes 1 .. np-2
+        if (q < np - 1) {
+            const int pass = np - 1 - q;
+            const int R = P.r1[pass] * P.r2[pass], nb = N / R;
+            const int bb = min(b, nb - 1);
+            const int blk = (int)__umulhi((unsigned)bb, P.imagic[q]);
+            const int k = bb - blk * Ns;
+            c.w[(NW - 1) / 2 + q] = tw[k * (nb / Ns)];
             Ns *= R;
         }
     }
 }
 // after_first() runs when the first forward pass has consumed its inputs: the caller re-uses their
 // registers for the next request there.
-template <int MAXR, unsigned MASK, typename T, typename First, typename After, typename Store>
+template <int MAXR, unsigned MASK, typename T, int NW, typename First, typename After, typename Store>
 __device__ __forceinline__ void filter_rows_hoisted(typename Vec2<T>::type *x, const First &first, const After &after_first,
                                                     const Store &store, const typename Vec2<T>::type *tw, const SuperPlan &P,
-                                                    int N, const FilterConsts<T> &c, int tid) {
+                                                    int N, const FilterConsts<T, NW> &c, int tid) {
     using V = typename Vec2<T>::type;
+    constexpr int kInv = (NW - 1) / 2;                            // w[kInv + q]: inverse pass q
     const auto reg_src = [&first](int i, int m) { return first(i, m); };
     const auto lds_src = [x](int i, int) { return x[i]; };
     const auto lds_dst = [x](int i, V v) { x[i] = v; };
     const T *sl = c.s;
-    const auto lds_src_filtered = [x, sl, N](int i, int) {
-        const T sv = sl[i <= N / 2 ? i : N - i];
-        const V v = x[i];
-        return mkv<V>(v.x * sv, v.y * sv);
-    };
+    const auto mult = [sl, N](int n) { return sl[n <= N / 2 ? n : N - n]; };
     const int np = P.npass;
-    const int R0 = P.r1[0] * P.r2[0];
-    // forward: pass 0 from registers, then up to three LDS passes
+    // (np >= 2: single-pass plans take the one-pair kernels -- the merged pass from registers to global
+    // memory, compiled in here, cost the looping kernel 40 registers whether it ran or not)
+    // forward: pass 0 from registers, then the LDS passes up to the merged one
     pass_dispatch<MAXR, MASK, false>(P.r1[0], P.r2[0], reg_src, lds_dst, false, tw, N, 1, P.magic[0], (const V *)nullptr, tid);
     after_first();
-    int Ns = R0;
-    if (np > 1) { pass_dispatch<MAXR, MASK, false>(P.r1[1], P.r2[1], lds_src, lds_dst, true, tw, N, Ns, P.magic[1], &c.w[0], tid); Ns *= P.r1[1] * P.r2[1]; }
-    if (np > 2) { pass_dispatch<MAXR, MASK, false>(P.r1[2], P.r2[2], lds_src, lds_dst, true, tw, N, Ns, P.magic[2], &c.w[1], tid); Ns *= P.r1[2] * P.r2[2]; }
-    if (np > 3) { pass_dispatch<MAXR, MASK, false>(P.r1[3], P.r2[3], lds_src, lds_dst, true, tw, N, Ns, P.magic[3], &c.w[2], tid); }
-    // inverse: pass 0 applies the multiplier; the last pass stores
-    if (np == 1) {
-        pass_dispatch<MAXR, MASK, true>(P.r1[0], P.r2[0], lds_src_filtered, store, false, tw, N, 1, P.magic[0], (const V *)nullptr, tid);
-        return;
-    }
-    pass_dispatch<MAXR, MASK, true>(P.r1[0], P.r2[0], lds_src_filtered, lds_dst, true, tw, N, 1, P.magic[0], (const V *)nullptr, tid);
-    Ns = R0;
-    if (np == 2) { pass_dispatch<MAXR, MASK, true>(P.r1[1], P.r2[1], lds_src, store, false, tw, N, Ns, P.magic[1], &c.w[0], tid); return; }
-    pass_dispatch<MAXR, MASK, true>(P.r1[1], P.r2[1], lds_src, lds_dst, true, tw, N, Ns, P.magic[1], &c.w[0], tid);
-    Ns *= P.r1[1] * P.r2[1];
-    if (np == 3) { pass_dispatch<MAXR, MASK, true>(P.r1[2], P.r2[2], lds_src, store, false, tw, N, Ns, P.magic[2], &c.w[1], tid); return; }
-    pass_dispatch<MAXR, MASK, true>(P.r1[2], P.r2[2], lds_src, lds_dst, true, tw, N, Ns, P.magic[2], &c.w[1], tid);
-    Ns *= P.r1[2] * P.r2[2];
-    pass_dispatch<MAXR, MASK, true>(P.r1[3], P.r2[3], lds_src, store, false, tw, N, Ns, P.magic[3], &c.w[2], tid);
+    int Ns = P.r1[0] * P.r2[0];
+    if (np > 2) { pass_dispatch<MAXR, MASK, false>(P.r1[1], P.r2[1], lds_src, lds_dst, true, tw, N, Ns, P.magic[1], &c.w[1], tid); Ns *= P.r1[1] * P.r2[1]; }
+    if constexpr (NW > 3)
+        if (np > 3) { pass_dispatch<MAXR, MASK, false>(P.r1[2], P.r2[2], lds_src, lds_dst, true, tw, N, Ns, P.magic[2], &c.w[2], tid); }
+    merged_dispatch<MAXR, MASK, V>(P.r1[np - 1], P.r2[np - 1], lds_src, lds_dst, true, true, mult, tw, N, &c.w[0], tid);
+    // inverse passes 1 .. np-1 (radices reversed); the last one stores
+    Ns = P.r1[np - 1] * P.r2[np - 1];
+    if (np > 2) { pass_dispatch<MAXR, MASK, true>(P.r1[np - 2], P.r2[np - 2], lds_src, lds_dst, true, tw, N, Ns, P.imagic[1], &c.w[kInv + 1], tid); Ns *= P.r1[np - 2] * P.r2[np - 2]; }
+    if constexpr (NW > 3)
+        if (np > 3) { pass_dispatch<MAXR, MASK, true>(P.r1[1], P.r2[1], lds_src, lds_dst, true, tw, N, Ns, P.imagic[2], &c.w[kInv + 2], tid); Ns *= P.r1[1] * P.r2[1]; }
+    pass_dispatch<MAXR, MASK, true>(P.r1[0], P.r2[0], lds_src, store, false, tw, N, Ns, P.imagic[np - 1], &c.w[0], tid);
 }
 
 // generic path: filter two real rows held as re/im of x[0..N): FFT, multiply by S[n] (n folded),
@@ -515,6 +585,11 @@ inline void make_super_plan(int n, SuperPlan *P) {
         --hi;
     }
     if (widest > 512) return;
+    Ns = 1;
+    for (int q = 0; q < P->npass; ++q) {                        // the inverse runs the radices in reversed order
+        P->imagic[q] = (unsigned)(((1ULL << 32) + (unsigned long long)Ns - 1) / (unsigned long long)Ns);
+        Ns *= (long)P->r1[P->npass - 1 - q] * P->r2[P->npass - 1 - q];
+    }
     P->threads = (widest + 63) / 64 * 64;
     P->ok = 1;
 }

@@ -51,8 +51,10 @@ __global__ __launch_bounds__(512) void pe_spu_filter_kernel(PeArgsT<T> a) {
 // before the current pair is transformed (two register sets that swap by name), so the only waits
 // left inside the loop are LDS round trips and barriers.
 // NIN: radix of the plan's first pass (inputs per thread) where the instantiation knows it, else MAXR
-template <typename T, int MAXR, unsigned MASK = 0, int NIN = MAXR>
-__global__ __launch_bounds__(512) void pe_spu_filter_loop_kernel(PeArgsT<T> a, int pairs_per_wg, int pit_block) {
+// NW: base twiddles kept in registers (FilterConsts): 3 for plans of up to three passes, 5 for four
+template <typename T, int MAXR, unsigned MASK = 0, int NIN = MAXR, int NW = 5>
+__global__ __launch_bounds__(512)
+void pe_spu_filter_loop_kernel(PeArgsT<T> a, int pairs_per_wg, int pit_block) {
     using V = typename Vec2<T>::type;
     extern __shared__ unsigned char lds_raw[];
     V *x = (V *)lds_raw;
@@ -110,8 +112,8 @@ __global__ __launch_bounds__(512) void pe_spu_filter_loop_kernel(PeArgsT<T> a, i
             }
         }
     }
-    FilterConsts<T> c;
-    filter_consts<T>(c, a.tw, a.cplan, W);
+    FilterConsts<T, NW> c;
+    filter_consts<T, NW>(c, a.tw, a.cplan, W);
     c.s = sl;
     __syncthreads();
     for (int pair = pb0; pair < pb1; ++pair) {
@@ -123,9 +125,9 @@ __global__ __launch_bounds__(512) void pe_spu_filter_loop_kernel(PeArgsT<T> a, i
         // hoisted out of the loop and held in hundreds of registers.
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        FilterConsts<T> cc = c;
+        FilterConsts<T, NW> cc = c;
 #pragma unroll
-        for (int n = 0; n < 3; ++n) asm volatile("" : "+v"(cc.w[n].x), "+v"(cc.w[n].y));
+        for (int n = 0; n < NW; ++n) asm volatile("" : "+v"(cc.w[n].x), "+v"(cc.w[n].y));
         const auto first = [&](int i, int m) {
             const T p = pe[i];
             return mkv<V>(in[m < NIN ? m : 0].x * p, in[m < NIN ? m : 0].y * p);
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(512) void pe_spu_filter_loop_kernel(PeArgsT<T> a, i
             o0[i] = v.x;
             if (two) o0[W + i] = v.y;
         };
-        filter_rows_hoisted<MAXR, MASK, T>(x, first, after_first, store, a.tw, a.cplan, W, cc, tid);
+        filter_rows_hoisted<MAXR, MASK, T, NW>(x, first, after_first, store, a.tw, a.cplan, W, cc, tid);
     }
 }
 
@@ -153,10 +155,10 @@ FilterKernel<T> spu_filter_kernel_for(const SuperPlan &P) {
 }
 template <typename T>
 FilterLoopKernel<T> spu_filter_loop_kernel_for(const SuperPlan &P) {
-    if (!P.ok || P.npass > 4) return nullptr;
+    if (!P.ok || P.npass > 4 || P.npass < 2) return nullptr;
     // the plans these masks stand for start with a pass of radix 5.2 / 5.3 / 4.4 (make_super_plan)
-    if (P.mask == kMask1440 && P.r1[0] * P.r2[0] == 10) return pe_spu_filter_loop_kernel<T, 12, kMask1440, 10>;
-    if (P.mask == kMask2880 && P.r1[0] * P.r2[0] == 15) return pe_spu_filter_loop_kernel<T, 16, kMask2880, 15>;
+    if (P.mask == kMask1440 && P.r1[0] * P.r2[0] == 10 && P.npass <= 3) return pe_spu_filter_loop_kernel<T, 12, kMask1440, 10, 3>;
+    if (P.mask == kMask2880 && P.r1[0] * P.r2[0] == 15 && P.npass <= 3) return pe_spu_filter_loop_kernel<T, 16, kMask2880, 15, 3>;
     if (P.mask == kMask1440) return pe_spu_filter_loop_kernel<T, 12, kMask1440>;
     if (P.mask == kMask2880) return pe_spu_filter_loop_kernel<T, 16, kMask2880>;
     if (P.mask == kMask4096) return pe_spu_filter_loop_kernel<T, 16, kMask4096>;
