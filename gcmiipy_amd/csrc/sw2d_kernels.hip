@@ -226,7 +226,11 @@ struct Raw {
     double u, v, p, t, q;
 };
 
-template <bool TEMP, int TRACER, bool WRAPJ>
+// STREAM: the base state is read with nontemporal loads -- a grid far larger than the caches is read once
+// per step (plus halo columns / band-edge rows), and the streaming hint is worth 1.5-2 % there (A/B on C3,
+// two boxes); nontemporal STORES cost 2-8 % (a strip's 480-byte rows share their edge lines with the
+// neighbouring strips, which only the L2 merges), so the results are stored normally.
+template <bool TEMP, int TRACER, bool WRAPJ, bool STREAM = false>
 struct FusedCtx {
     const Sw2dArgs &a;
     const double *tab;
@@ -237,11 +241,19 @@ struct FusedCtx {
     __device__ __forceinline__ Raw load(int j) const {
         const long o = row_off(j, a.H, a.W, WRAPJ) + ci;
         Raw r;
-        r.u = a.bu[o];
-        r.v = a.bv[o];
-        r.p = a.bp[o];
-        r.t = TEMP ? a.bt[o] : 0.0;
-        r.q = TRACER ? a.bq[o] : 0.0;
+        if (STREAM) {
+            r.u = __builtin_nontemporal_load(&a.bu[o]);
+            r.v = __builtin_nontemporal_load(&a.bv[o]);
+            r.p = __builtin_nontemporal_load(&a.bp[o]);
+            r.t = TEMP ? __builtin_nontemporal_load(&a.bt[o]) : 0.0;
+            r.q = TRACER ? __builtin_nontemporal_load(&a.bq[o]) : 0.0;
+        } else {
+            r.u = a.bu[o];
+            r.v = a.bv[o];
+            r.p = a.bp[o];
+            r.t = TEMP ? a.bt[o] : 0.0;
+            r.q = TRACER ? a.bq[o] : 0.0;
+        }
         return r;
     }
 
@@ -323,7 +335,7 @@ __device__ __forceinline__ void preloaded_iters(Ctx &c, const Raw (&pre)[PRE + 4
     }
 }
 
-template <bool TEMP, int TRACER, bool WRAPJ, int PRE = 0>
+template <bool TEMP, int TRACER, bool WRAPJ, int PRE = 0, bool STREAM = false>
 __global__ __launch_bounds__(64) void sw2d_fused_kernel(Sw2dArgs a) {
     const int W = a.W;
     const int lane = threadIdx.x;
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(64) void sw2d_fused_kernel(Sw2dArgs a) {
         for (int k = 0; k < kExnerTabDoubles / 64; ++k) tab[lane + 64 * k] = a.exner_tab[lane + 64 * k];
         __syncthreads();
     }
-    FusedCtx<TEMP, TRACER, WRAPJ> c{a, tab};
+    FusedCtx<TEMP, TRACER, WRAPJ, STREAM> c{a, tab};
     c.ja = a.j0 + band * a.rows_per_band;
     c.jb = min(c.ja + a.rows_per_band, a.j1);
     if (c.ja >= c.jb) return;   // also the padding tiles beyond the last band
@@ -519,21 +531,25 @@ bool launch_sw2d_fused2(const Sw2dArgs &a, hipStream_t s) {
 constexpr int kPreloadRows = 4;     // bands of up to this many rows use the preloading variant (plain SW2D)
 
 template <bool TEMP, int TRACER>
-static const void *fused_fn(bool wrap) {
+static const void *fused_fn(bool wrap, bool stream) {
+    if (stream)
+        return wrap ? (const void *)sw2d_fused_kernel<TEMP, TRACER, true, 0, true>
+                    : (const void *)sw2d_fused_kernel<TEMP, TRACER, false, 0, true>;
     return wrap ? (const void *)sw2d_fused_kernel<TEMP, TRACER, true>
                 : (const void *)sw2d_fused_kernel<TEMP, TRACER, false>;
 }
 
-static const void *fused_kernel_ptr(bool temp, int tracer, bool wrap, int rows_per_band = 1 << 30) {
+// stream: the rows this launch reads are far more than the caches hold (see FusedCtx)
+static const void *fused_kernel_ptr(bool temp, int tracer, bool wrap, int rows_per_band = 1 << 30, bool stream = false) {
     if (!temp) {
         if (rows_per_band <= kPreloadRows)
             return wrap ? (const void *)sw2d_fused_kernel<false, 0, true, kPreloadRows>
                         : (const void *)sw2d_fused_kernel<false, 0, false, kPreloadRows>;
-        return fused_fn<false, 0>(wrap);
+        return fused_fn<false, 0>(wrap, stream);
     }
-    if (tracer == 0) return fused_fn<true, 0>(wrap);
-    if (tracer == 1) return fused_fn<true, 1>(wrap);
-    return fused_fn<true, 2>(wrap);
+    if (tracer == 0) return fused_fn<true, 0>(wrap, stream);
+    if (tracer == 1) return fused_fn<true, 1>(wrap, stream);
+    return fused_fn<true, 2>(wrap, stream);
 }
 
 // Rows per wave.  Large grids: one resident round -- as many waves as the chip holds at
@@ -573,7 +589,10 @@ bool launch_sw2d_fused(const Sw2dArgs &a, bool temp, int tracer, hipStream_t s) 
     dim3 g((unsigned)(((long)strips * bands + 7) / 8 * 8));  // 1-D, padded to 8 XCD groups
     Sw2dArgs arg = a;
     void *params[] = {&arg};
-    return hipLaunchKernel(fused_kernel_ptr(temp, tracer, a.wrap_j != 0, a.rows_per_band), g, dim3(64), params, 0, s) == hipSuccess;
+    // fields x 8 bytes x the rows of this launch, read once: stream it when that is beyond the 256 MB Infinity Cache
+    const int nfields = 3 + (temp ? 1 : 0) + (tracer ? 1 : 0);
+    const bool stream = (long)a.W * (a.j1 - a.j0) * 8 * nfields > (256L << 20);
+    return hipLaunchKernel(fused_kernel_ptr(temp, tracer, a.wrap_j != 0, a.rows_per_band, stream), g, dim3(64), params, 0, s) == hipSuccess;
 }
 
 __global__ void copy_rows_kernel(double *dst, const double *src, long n) {
