@@ -146,9 +146,10 @@ __device__ V *fft_lds(V *x, V *y, const V *tw, const FftPlan &P) {
 // passes per direction instead of six, each thread does ONE R-point butterfly per pass entirely in
 // registers (Cooley-Tukey split into R2 butterflies of radix R1, the W_R twiddles, R1 butterflies
 // of radix R2), and a workgroup has only as many threads as the widest pass has butterflies.
-// The first forward pass reads its inputs straight from global memory (a functor), the first
-// inverse pass applies the filter multiplier while it reads, the last inverse pass stores to
-// global memory: LDS holds one row of complex values and is touched once per pass.
+// The first forward pass reads its inputs straight from global memory (a functor), the last forward
+// pass, the filter multiplier and the first inverse pass are one step in registers (merged_pass: the
+// inverse runs the radices in reversed order), the last inverse pass stores to global memory: LDS
+// holds one row of complex values and is touched once between two passes.
 template <int R, bool INV, typename V>
 __device__ __forceinline__ void butterfly(V (&v)[R]) {
     using T = Sc<V>;
