@@ -114,6 +114,33 @@ __global__ __launch_bounds__(64) void strip_pitch_k(double *const *dst, const do
         for (int f = 0; f < NF; ++f) cur[f] = nxt[f];
     }
 }
+// the strip march southwards (up = 0) or northwards (up = 1): consecutive steps ping-pong src / dst as the model does;
+// alternating the direction lets a step begin on the rows the previous one touched last (Infinity Cache reuse?)
+template <int NF>
+__global__ __launch_bounds__(64) void strip_dir_k(double *const *dst, const double *const *src, int W, int H, int rows_per_band, int up, int rev = 0) {
+    // 13 KB of LDS per wave: 12 waves per CU, the residency of the real kernel (3 per SIMD), so that a grid of more
+    // than 3072 waves runs in rounds, in workgroup-id order
+    __shared__ double occ[1664];
+    occ[threadIdx.x] = 0.0;
+    const int strips = W / 64;
+    const int tile = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int band = tile / strips, i = (tile % strips) * 64 + threadIdx.x;
+    const int j0 = band * rows_per_band, j1 = min(H, j0 + rows_per_band);
+    const int n = j1 - j0;
+    const auto row = [&](int t) { return up ? j1 - 1 - t : j0 + t; };
+    double cur[NF], nxt[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) cur[f] = src[f][(long)row(0) * W + i];
+    for (int t = 0; t < n; ++t) {
+        const int jn = row(min(t + 1, n - 1));
+#pragma unroll
+        for (int f = 0; f < NF; ++f) nxt[f] = src[f][(long)jn * W + i];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) dst[f][(long)row(t) * W + i] = cur[f] * 1.0000001;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) cur[f] = nxt[f];
+    }
+}
 int main() {
     const int W = 4096, H = 2048, NF = 5;
     const long n = (long)W * H;            // doubles per field
@@ -201,6 +228,37 @@ int main() {
         RUN3("strip3: reads row by row (nt), writes 12 rows at a time", NF, 12, true, false);
         RUN3("strip3: reads row by row (nt), writes 8 rows at a time (nt)", NF, 8, true, true);
 #undef RUN3
+        {
+            int step = 0;
+            const double *const *csd = (const double *const *)dd;
+            time("ping-pong steps, every step southwards", [&] {
+                if (step++ & 1) hipLaunchKernelGGL((strip_dir_k<NF>), g, b, 0, 0, ds, csd, W, H, rpb, 0);
+                else hipLaunchKernelGGL((strip_dir_k<NF>), g, b, 0, 0, dd, cs, W, H, rpb, 0);
+            });
+            for (int rr : {47, 24, 16}) {
+                const dim3 g2((W / 64) * ((H + rr - 1) / rr));
+                char nm[128];
+                snprintf(nm, sizeof nm, "ping-pong steps, %d rows per band (%d waves, 3072 resident), same tile order", rr, (int)g2.x);
+                step = 0;
+                time(nm, [&] {
+                    if (step++ & 1) hipLaunchKernelGGL((strip_dir_k<NF>), g2, b, 0, 0, ds, csd, W, H, rr, 0, 0);
+                    else hipLaunchKernelGGL((strip_dir_k<NF>), g2, b, 0, 0, dd, cs, W, H, rr, 0, 0);
+                });
+                snprintf(nm, sizeof nm, "ping-pong steps, %d rows per band, tile order reversed every other step", rr);
+                step = 0;
+                time(nm, [&] {
+                    const int rv = step & 1;
+                    if (step++ & 1) hipLaunchKernelGGL((strip_dir_k<NF>), g2, b, 0, 0, ds, csd, W, H, rr, 0, rv);
+                    else hipLaunchKernelGGL((strip_dir_k<NF>), g2, b, 0, 0, dd, cs, W, H, rr, 0, rv);
+                });
+            }
+            step = 0;
+            time("ping-pong steps, direction alternating", [&] {
+                const int up = step & 1;
+                if (step++ & 1) hipLaunchKernelGGL((strip_dir_k<NF>), g, b, 0, 0, ds, csd, W, H, rpb, up);
+                else hipLaunchKernelGGL((strip_dir_k<NF>), g, b, 0, 0, dd, cs, W, H, rpb, up);
+            });
+        }
         // row pitch: arrays re-based at (n + slack) doubles apart so that a padded pitch fits
         for (int pad : {0, 16, 32, 512}) {   // H * pad <= slack
             const int P = W + pad;
