@@ -70,6 +70,7 @@ SYMBOLS = {
     "gcm_device_count": (C.c_int, []),
     "gcm_build_info": (C.c_char_p, []),
     "gcm_exner_table": (C.c_int, [_dp]),
+    "gcm_filter_plan": (C.c_int, [C.c_int, C.POINTER(C.c_uint), C.c_int]),
     "gcm_create": (C.c_int, [C.POINTER(Config), C.POINTER(_H)]),
     "gcm_destroy": (C.c_int, [_H]),
     "gcm_last_error": (C.c_char_p, [_H]),

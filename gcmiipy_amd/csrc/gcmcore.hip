@@ -121,6 +121,8 @@ int gcm_exner_table(double *out256) {
     return GCM_OK;
 }
 
+int gcm_filter_plan(int n, unsigned *out, int cap) { return pe25d_filter_plan(n, out, cap); }
+
 const char *gcm_last_error(const gcm_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int gcm_destroy(gcm_handle *h) {

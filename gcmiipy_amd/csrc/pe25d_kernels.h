@@ -38,6 +38,7 @@ int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, do
                     const double *lat, const double *lon, double *dTdt_host, double *dtg_host,
                     hipStream_t s, std::string *err);
 int pe25d_stats(Pe25d *m, const double *area_host, int area_len, double out[9], hipStream_t s, std::string *err);
+int pe25d_filter_plan(int n, unsigned *out, int cap);   // gcm_filter_plan
 void pe25d_tv_shape(const Pe25d *m, int field, long *n_outer, long *n_axis, long *n_inner, int *wrap);
 const void *pe25d_field(Pe25d *m, int field, long *n, int *f32);
 void pe25d_timing(Pe25d *m, std::vector<hipEvent_t> *ev, size_t *used);

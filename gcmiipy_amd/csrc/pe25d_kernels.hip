@@ -1606,6 +1606,22 @@ int pe25d_stats(Pe25d *m, const double *area_host, int area_len, double out[9], 
 
 // field geometry for get_total_variation (axis 0 of the reference layout): 2-D p differences rows,
 // the 3-D fields difference levels inside a row slab
+int pe25d_filter_plan(int n, unsigned *out, int cap) {
+    if (!out || n < 2 || cap < 3 + 4 * kMaxSuper) return GCM_ERR_ARG;
+    SuperPlan P;
+    make_super_plan(n, &P);
+    out[0] = (unsigned)P.ok;
+    out[1] = (unsigned)P.npass;
+    out[2] = (unsigned)P.threads;
+    for (int p = 0; p < kMaxSuper; ++p) {
+        out[3 + 4 * p] = (unsigned)P.r1[p];
+        out[4 + 4 * p] = (unsigned)P.r2[p];
+        out[5 + 4 * p] = P.magic[p];
+        out[6 + 4 * p] = P.imagic[p];
+    }
+    return GCM_OK;
+}
+
 void pe25d_tv_shape(const Pe25d *m, int field, long *n_outer, long *n_axis, long *n_inner, int *wrap) {
     if (field == GCM_P) { *n_outer = 1; *n_axis = m->H; *n_inner = m->W; *wrap = m->wrap ? 1 : 0; }
     else { *n_outer = m->H; *n_axis = m->L; *n_inner = m->W; *wrap = 1; }

@@ -119,6 +119,13 @@ const char *gcm_build_info(void);           /* compiler, offload arch, build fla
 /* The 256-double table the kernels use for (p/P0)**kappa (temperature.py:7-19): lets a host
  * test check the device algorithm's accuracy without a GPU.  Returns 0. */
 int gcm_exner_table(double *out256);
+/* The composite-radix plan of the polar filter's in-LDS transform (low_pass.py:41-78 does numpy.fft.rfft /
+ * irfft; csrc/fft_lds.h) for rows of n columns, so that a host test can replay the passes' index arithmetic
+ * without a GPU.  out[0] = 1 if the composite path serves n (0: generic mixed-radix path), out[1] = passes,
+ * out[2] = threads per workgroup, then four words per pass: r1, r2 (the pass has radix r1 * r2),
+ * magic = ceil(2^32 / Ns) of the forward pass, imagic = the same for the inverse transform, whose passes take
+ * the radices in reversed order.  cap = words available in out (>= 3 + 4 * 8).  Returns 0. */
+int gcm_filter_plan(int n, unsigned *out, int cap);
 
 /* Lifetime.  Device buffers are library-owned inside the handle. */
 int gcm_create(const gcm_config *cfg, gcm_handle **out);
