@@ -309,6 +309,7 @@ __global__ __launch_bounds__(256) void pe_energy_kernel(PeArgs a, const double *
 template <typename T>
 struct RadArgsT {
     const double *tlw, *tsw, *csw_top, *clw_b_div, *swfac;   // [L] level tables (host-built)
+    const double *sigk;                                      // [L] sig^kappa (FACT, see pe_radiation_kernel)
     const double *coslat, *sinlat, *lon;                     // [Hg], [Hg], [W]
     double *gt;                                              // ground temperature [H][W]
     T *dTdt, *dtg;                                           // tendencies out of the diagnostic form (3-D, 2-D scratch)
@@ -325,9 +326,14 @@ struct RadArgsT {
 // LMAX > 0: L <= LMAX and the parked column lives in registers (loops unrolled); LMAX == 0: any L,
 // parked in LDS, park[L][threads].  The kernel reads theta and writes it (apply) or dTdt (diagnostic);
 // nothing else goes through HBM.
+// FACT (ptop == 0, the reference's geometry): the Exner factor of level k is (p sig_k / P0)^kappa =
+// (p / P0)^kappa sig_k^kappa -- ONE table-and-series evaluation per column and a product per use instead of
+// three evaluations per level (emission in either scan, to_potential_temp); sig^kappa comes from the host in
+// extended precision.  The product differs from the direct evaluation by an ulp or two of a factor that enters
+// theta -> T -> theta symmetrically, far inside the 1e-10 of the parity tests (golden g13, the 2880x1440x40 strips).
 constexpr int kRadThreads = 128;
-constexpr int kRadTabs = 7;      // per level: tlw, clw_b_div, swfac, sig, dsig, 1 - tlw, G / (Cp dsig)
-template <typename T, int LMAX>
+constexpr int kRadTabs = 7;      // per level: tlw, clw_b_div, swfac, sig, dsig, sig^kappa, (free)
+template <typename T, int LMAX, bool FACT = false>
 __global__ __launch_bounds__(kRadThreads) void pe_radiation_kernel(PeArgsT<T> a, RadArgsT<T> r, T *t_inout) {
     __shared__ double tab[kExnerTabDoubles];
     __shared__ double lev[kRadTabs][LMAX > 0 ? LMAX : 1];
@@ -341,6 +347,7 @@ __global__ __launch_bounds__(kRadThreads) void pe_radiation_kernel(PeArgsT<T> a,
             const int kk = min(k, L - 1);
             lev[0][k] = r.tlw[kk]; lev[1][k] = r.clw_b_div[kk]; lev[2][k] = r.swfac[kk];
             lev[3][k] = (double)a.sig[kk]; lev[4][k] = (double)a.dsig[kk];
+            if (FACT) lev[5][k] = r.sigk[kk];
         }
     }
     __syncthreads();
@@ -372,11 +379,12 @@ __global__ __launch_bounds__(kRadThreads) void pe_radiation_kernel(PeArgsT<T> a,
     const auto swf = [&](int k) { return LMAX > 0 ? lev[2][k] : r.swfac[k]; };
     const auto sig = [&](int k) { return LMAX > 0 ? lev[3][k] : (double)a.sig[k]; };
     const auto dsg = [&](int k) { return LMAX > 0 ? lev[4][k] : (double)a.dsig[k]; };
+    const double ex_col = FACT ? exner(pc, tab) : 0.0;
+    const auto exk = [&](int k) { return FACT ? ex_col * lev[5][LMAX > 0 ? k : 0] : exner(pc * sig(k) + ptop, tab); };
     // true temperature and emission of one level (to_true_temp; grey_solar.py emission)
     const auto emission = [&](int k, double *tt_out) {
-        const double tp = pc * sig(k) + ptop;
         const double th = LMAX > 0 ? (double)tcol[LMAX > 0 ? k : 0] : (double)t_inout[c3 + (long)k * W];
-        const double tt = th * exner(tp, tab);
+        const double tt = th * exk(k);
         const double t2 = tt * tt;
         *tt_out = tt;
         return (1 - tlw(k)) * kSb * (t2 * t2);
@@ -411,9 +419,8 @@ __global__ __launch_bounds__(kRadThreads) void pe_radiation_kernel(PeArgsT<T> a,
         const double lwb = LMAX > 0 ? lwb_reg[k] : p_lwb[k * kRadThreads];
         const double dTdt = (U_n + S_n - 2 * em + lwa + lwb) * (kG / (kCp * pc * dsg(k)));
         if (r.apply) {
-            const double tp = pc * sig(k) + ptop;
             const double tt_n = tt + dTdt * r.dt;
-            t_inout[o] = (T)(tt_n * rcp(exner(tp, tab)));          // to_potential_temp
+            t_inout[o] = (T)(tt_n * rcp(exk(k)));                  // to_potential_temp
         } else {
             r.dTdt[o] = (T)dTdt;
         }
@@ -466,6 +473,7 @@ struct Pe25d {
     bool wrap = true, f32 = false;
     std::vector<void *> allocs;
     std::vector<double> dsig_host;              // geometry.py dsig, float64 (radiation level tables)
+    std::vector<double> sig_host;               // geometry.py sig, float64
     PeBufs<double> d;
     PeBufs<float> f;
     int cur_i = 0;
@@ -733,6 +741,7 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
     m->wrap = cfg.nranks == 1;
     m->f32 = cfg.dtype == GCM_F32;
     m->dsig_host.assign(cfg.dsig, cfg.dsig + cfg.layers);
+    m->sig_host.assign(cfg.sig, cfg.sig + cfg.layers);
     const int W = m->W, L = m->L;
     auto bad = [&](const char *what) {
         *err = std::string("hip: GCM_PE25D allocation/upload failed: ") + what;
@@ -1469,6 +1478,7 @@ static int radiation_launch(Pe25d *m, bool apply, double dt, double hour_angle, 
     PeArgsT<T> a = make_args<T>(m, m->cur_i, m->cur_i, dt);
     RadArgsT<T> r{};
     r.tlw = m->rad_tab; r.tsw = r.tlw + L; r.csw_top = r.tsw + L; r.clw_b_div = r.csw_top + L; r.swfac = r.clw_b_div + L;
+    r.sigk = r.swfac + L;
     r.coslat = m->rad_geo; r.sinlat = m->rad_geo + Hg; r.lon = m->rad_geo + 2 * Hg;
     r.gt = m->gt;
     r.dTdt = B.pgfu; r.dtg = B.pit;
@@ -1479,7 +1489,10 @@ static int radiation_launch(Pe25d *m, bool apply, double dt, double hour_angle, 
         const dim3 gg((W + kRadThreads - 1) / kRadThreads, H);
         T *th = B.st[m->cur_i][GCM_T];
         static const bool generic = getenv("GCM_PE_RAD_GENERIC") != nullptr;     // diagnostic: the LDS-parked form
-        if (L <= 24 && !generic) hipLaunchKernelGGL((pe_radiation_kernel<T, 24>), gg, dim3(kRadThreads), 0, s, a, r, th);
+        const bool fact = m->cfg.ptop == 0.0 && r.sigk != nullptr;
+        if (L <= 24 && !generic && fact) hipLaunchKernelGGL((pe_radiation_kernel<T, 24, true>), gg, dim3(kRadThreads), 0, s, a, r, th);
+        else if (L <= 40 && !generic && fact) hipLaunchKernelGGL((pe_radiation_kernel<T, 40, true>), gg, dim3(kRadThreads), 0, s, a, r, th);
+        else if (L <= 24 && !generic) hipLaunchKernelGGL((pe_radiation_kernel<T, 24>), gg, dim3(kRadThreads), 0, s, a, r, th);
         else if (L <= 40 && !generic) hipLaunchKernelGGL((pe_radiation_kernel<T, 40>), gg, dim3(kRadThreads), 0, s, a, r, th);
         else hipLaunchKernelGGL((pe_radiation_kernel<T, 0>), gg, dim3(kRadThreads), sizeof(double) * (size_t)L * kRadThreads, s, a, r, th);
     }
@@ -1513,7 +1526,7 @@ int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, do
     if (m->rad_key[0] != t_lw || m->rad_key[1] != t_sw || !m->rad_tab) {
         // level tables, same expression order as grey_solar.py:323-333,377-385,541
         std::vector<double> &T = m->rad_tab_host;
-        T.assign((size_t)5 * L, 0.0);
+        T.assign((size_t)6 * L, 0.0);
         const std::vector<double> &dsig = m->dsig_host;
         double *tlw = T.data(), *tsw = tlw + L, *csw = tsw + L, *cdiv = csw + L, *swf = cdiv + L;
         for (int k = 0; k < L; ++k) {
@@ -1524,13 +1537,14 @@ int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, do
         for (int k = L - 1; k >= 0; --k) { c = k == L - 1 ? tsw[k] : c * tsw[k]; csw[k] = c; }
         for (int k = 0; k < L; ++k) { c = k == 0 ? tlw[k] : c * tlw[k]; cdiv[k] = c / tlw[k]; }
         for (int k = 0; k < L; ++k) swf[k] = (1 - tsw[k]) * csw[k] / tsw[k];
-        if (!m->rad_tab && !dev_upload<double>(m, &m->rad_tab, nullptr, (size_t)5 * L)) {
+        for (int k = 0; k < L; ++k) swf[L + k] = (double)powl((long double)m->sig_host[k], (long double)kKappa);   // sig^kappa (FACT)
+        if (!m->rad_tab && !dev_upload<double>(m, &m->rad_tab, nullptr, (size_t)6 * L)) {
             *err = "hip: radiation table allocation failed"; return GCM_ERR_HIP;
         }
         // the host copy lives in the handle until the next change, so the asynchronous upload may
         // read it after this call returns; a change waits for the previous upload first
         if (hipStreamSynchronize(s) != hipSuccess ||
-            hipMemcpyAsync(m->rad_tab, T.data(), sizeof(double) * 5 * L, hipMemcpyHostToDevice, s) != hipSuccess) {
+            hipMemcpyAsync(m->rad_tab, T.data(), sizeof(double) * 6 * L, hipMemcpyHostToDevice, s) != hipSuccess) {
             *err = "hip: radiation table upload failed"; return GCM_ERR_HIP;
         }
         m->rad_key[0] = t_lw; m->rad_key[1] = t_sw;
