@@ -9,26 +9,12 @@ from . import _lib, geometry
 from .core import Core
 from .dynamics import _prep, _wrap_out, core_for
 from .units import scalar
+from .humidity import manabe_rh, saturation_vapor_pressure, rh_to_mmr, w_s_at, vmr_from_mmr, mmr_to_rh  # noqa: F401  (no_limits_2_5d.py:28: `from humidity import *`)
 
 Rd, Rv, P0, KAPPA = 287.0, 461.0, 100000.0, 287.0 / 1004.0     # constants.py:16,78,31,28
 
 GroundVars = namedtuple("GroundVars", ("gt", "gw", "snow", "ice"))   # no_limits_2_5d.py:143
 STATS = defaultdict(list)                                            # no_limits_2_5d.py:63
-
-
-def manabe_rh(geom):
-    return 0.77 * (geom.sig - 0.02) / (1 - 0.02)                    # humidity.py:4-7
-
-
-def saturation_vapor_pressure(tt):
-    t = tt - 273.15                                                  # humidity.py:10-14 (Buck, kPa -> Pa)
-    return 0.61121 * 1000.0 * np.exp((18.678 - t / 234.5) * (t / (257.14 + t)))
-
-
-def rh_to_mmr(rh, tp, tt):
-    e = rh * saturation_vapor_pressure(tt)                           # humidity.py:27-37
-    w = e * Rd / (Rv * (tp - e))
-    return w / (w + 1)
 
 
 def gen_initial_conditions(geom):

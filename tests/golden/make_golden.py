@@ -509,7 +509,33 @@ def g13_radiation():
     save("g13_radiation", **out)
 
 
+def g14_humidity():
+    """humidity.py: manabe_rh, the Buck saturation vapour pressure, mixing ratios and the rh <-> mmr pair"""
+    with contextlib.redirect_stdout(_sink):
+        import humidity
+    rng = np.random.default_rng(14)
+    geom = quiet(geometry.gen_geometry, 6, 8, 9, sig_func=geometry.manabe_sig)
+    n = 4000
+    tt = 200.0 + 130.0 * rng.random(n)                    # K
+    tp = 2000.0 + 101000.0 * rng.random(n)                # Pa
+    rh = 0.01 + 0.99 * rng.random(n)
+    # keep the vapour pressure below the total pressure (hot air at low pressure has no such state)
+    es = m(humidity.saturation_vapor_pressure(tt * U.K))
+    keep = es < 0.5 * tp
+    tt, tp, rh = tt[keep], tp[keep], rh[keep]
+    svp = humidity.saturation_vapor_pressure(tt * U.K)
+    ws = humidity.w_s_at(tp * U.Pa, tt * U.K)
+    mmr = humidity.rh_to_mmr(rh, tp * U.Pa, tt * U.K)
+    back = humidity.mmr_to_rh(mmr, tp * U.Pa, tt * U.K)
+    vmr = humidity.vmr_from_mmr(mmr, C.M_water, C.Md)
+    save("g14_humidity", sig=m(geom.sig), manabe_rh=m(humidity.manabe_rh(geom)), tt=tt, tp=tp, rh=rh,
+         svp=m(svp), w_s=m(ws), mmr=m(mmr), rh_back=m(back), vmr=m(vmr),
+         M_water=m(C.M_water), Md=m(C.Md))
+
+
 if __name__ == "__main__":
     for f in (g1_shifts, g2_sw2d, g3_sw2d_temp, g4_tracer, g5_geometry, g6_lowpass,
-              g7_half_step, g8_pe25d, g9_oned, g10_pe2d, g11_temperature, g12_coriolis, g13_radiation):
+              g7_half_step, g8_pe25d, g9_oned, g10_pe2d, g11_temperature, g12_coriolis, g13_radiation, g14_humidity):
+        if len(sys.argv) > 1 and f.__name__ not in sys.argv[1:]:
+            continue                                      # python make_golden.py g14_humidity: only that set
         f()

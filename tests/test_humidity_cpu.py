@@ -1,0 +1,80 @@
+"""humidity.py (reference :4-60): the oracle's restatement and the drop-in module against golden g14
+(generated from the reference's own humidity.py), and the reference's round-trip test."""
+import os
+import types
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "g14_humidity.npz")
+
+
+def _check(mod):
+    d = np.load(GOLD)
+    geom = types.SimpleNamespace(sig=d["sig"])
+    tt, tp, rh = d["tt"], d["tp"], d["rh"]
+    same = lambda a, b: np.array_equal(np.asarray(a), b)        # noqa: E731  (bit for bit: the same NumPy expressions)
+    assert same(mod.manabe_rh(geom), d["manabe_rh"])
+    assert same(mod.saturation_vapor_pressure(tt), d["svp"])
+    assert same(mod.w_s_at(tp, tt), d["w_s"])
+    mmr = mod.rh_to_mmr(rh, tp, tt)
+    assert same(mmr, d["mmr"])
+    assert same(mod.mmr_to_rh(mmr, tp, tt), d["rh_back"])
+    assert same(mod.vmr_from_mmr(mmr, float(d["M_water"]), float(d["Md"])), d["vmr"])
+
+
+def test_oracle_humidity_matches_golden():
+    from oracle import humidity
+    _check(humidity)
+
+
+def test_dropin_humidity_matches_golden():
+    from gcmiipy_amd import humidity
+    _check(humidity)
+
+
+def test_round_trip_of_the_reference():
+    """humidity.py:63-86 (test_humidity_calcs): rh -> mmr -> rh within 1e-6 for 0..100 C, 10..1000 hPa, rh 0.1..1"""
+    from gcmiipy_amd import humidity
+    t = (np.arange(101) + 273.15)[:, None, None]
+    p = ((np.arange(100) + 1) * 10 * 100.0)[None, :, None]
+    rh = ((np.arange(10) + 1) / 10)[None, None, :]
+    mmr = humidity.rh_to_mmr(rh, p, t)
+    back = humidity.mmr_to_rh(mmr, p, t)
+    assert np.all(np.abs(rh - back) < 1e-6)
+
+
+def test_quantities_are_accepted():
+    """pint-like arguments (anything with .to_base_units() and .m) are reduced to SI magnitudes"""
+    from gcmiipy_amd import humidity
+
+    class Q:
+        def __init__(self, v, scale=1.0):
+            self.v, self.scale = np.asarray(v, dtype=float), scale
+
+        def to_base_units(self):
+            return Q(self.v * self.scale)
+
+        @property
+        def m(self):
+            return self.v
+
+        @property
+        def units(self):
+            return None
+
+    tt, tp = np.array([280.0, 300.0]), np.array([90000.0, 100000.0])
+    a = humidity.rh_to_mmr(0.5, Q(tp / 100.0, 100.0), Q(tt))        # hPa and K
+    assert np.array_equal(a, humidity.rh_to_mmr(0.5, tp, tt))
+    # the harness builds its humidity field from these (no_limits_2_5d.py:160-166)
+    from gcmiipy_amd import no_limits_2_5d
+    assert no_limits_2_5d.rh_to_mmr is humidity.rh_to_mmr
+
+
+def test_initial_conditions_still_match_golden():
+    """gen_initial_conditions goes through the module now: golden g8's harness state, bit for bit"""
+    from gcmiipy_amd import geometry, no_limits_2_5d
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "g8_pe25d.npz"))
+    geom = geometry.gen_geometry(24, 36, 9, sig_func=geometry.manabe_sig)
+    p, u, v, t, q, g = no_limits_2_5d.gen_initial_conditions(geom)
+    for k, x in zip(("p", "u", "v", "t", "q"), (p, u, v, t, q)):
+        assert np.array_equal(x, d["ic_24_36_9_" + k]), k
