@@ -1,6 +1,9 @@
 """Drop-in for the reference's grey-atmosphere column physics (grey_solar.py) and
 no_limits_2_5d.solar_timestep, computed by the HIP column kernel."""
+import math
 from collections import namedtuple
+
+import numpy as np
 
 from .dynamics import core_for
 from .core import as_f64
@@ -11,6 +14,20 @@ GroundVars = namedtuple("GroundVars", ("gt", "gw", "snow", "ice"))
 
 def _gt(g):
     return strip(g.gt if hasattr(g, "gt") else g)[0]
+
+
+def solar_zenith_angle(latitude, hour_angle, declination):
+    """grey_solar.py:39-46: cos(zenith angle) from latitude, hour angle and declination (radians).  Host NumPy,
+    for callers that want the field itself; the column kernel evaluates the same expression per column."""
+    return np.sin(latitude) * np.sin(declination) + np.cos(latitude) * np.cos(declination) * np.cos(hour_angle)
+
+
+def zenith_angle(longs, lats, time, geom):
+    """grey_solar.py:49-65: max(cos(zenith), 0) on the (height, width) grid at `time` seconds UTC."""
+    hour_angle = scalar(time) / (-24 * 3600.0) * 360 * (math.pi / 180)
+    t_longs = np.tile(strip(longs)[0], (geom.height, 1))
+    point_angle = t_longs + hour_angle
+    return np.maximum(solar_zenith_angle(strip(lats)[0], point_angle, 0 * (math.pi / 180)), 0)
 
 
 def basic_grey_radiation(p, tp, tt, g, t_lw, t_sw, albedo, utc, geom):

@@ -9,6 +9,7 @@ from . import _lib, geometry
 from .core import Core
 from .dynamics import _prep, _wrap_out, core_for
 from .units import scalar
+from .grey_solar import solar_timestep  # noqa: F401  (no_limits_2_5d.py:66-75 lives beside full_timestep in the reference)
 from .humidity import manabe_rh, saturation_vapor_pressure, rh_to_mmr, w_s_at, vmr_from_mmr, mmr_to_rh  # noqa: F401  (no_limits_2_5d.py:28: `from humidity import *`)
 
 Rd, Rv, P0, KAPPA = 287.0, 461.0, 100000.0, 287.0 / 1004.0     # constants.py:16,78,31,28

@@ -78,3 +78,15 @@ def test_initial_conditions_still_match_golden():
     p, u, v, t, q, g = no_limits_2_5d.gen_initial_conditions(geom)
     for k, x in zip(("p", "u", "v", "t", "q"), (p, u, v, t, q)):
         assert np.array_equal(x, d["ic_24_36_9_" + k]), k
+
+
+def test_zenith_angle_matches_golden():
+    """grey_solar.zenith_angle (host NumPy) against the reference's field in golden g13"""
+    from gcmiipy_amd import geometry, grey_solar, no_limits_2_5d
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "g13_radiation.npz"))
+    geom = geometry.gen_geometry(12, 20, 5, sig_func=geometry.manabe_sig)
+    for tag in "ab":
+        got = grey_solar.zenith_angle(geom.long, geom.lat, float(d["utc_" + tag]), geom)
+        assert got.shape == d["sza_" + tag].shape
+        assert np.max(np.abs(got - d["sza_" + tag])) < 1e-15
+    assert no_limits_2_5d.solar_timestep is grey_solar.solar_timestep      # no_limits_2_5d.py:66-75
