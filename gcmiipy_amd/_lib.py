@@ -63,6 +63,12 @@ class Exchange(C.Structure):
                 ("recv_south", C.c_void_p)]
 
 
+class Physics(C.Structure):
+    """gcm_physics of include/gcmcore.h"""
+    _fields_ = [("utc", C.c_double), ("t_lw", C.c_double), ("t_sw", C.c_double), ("albedo", C.c_double),
+                ("lat", _dp), ("lon", _dp)]
+
+
 _H = C.c_void_p
 # name -> (restype, argtypes); every symbol include/gcmcore.h declares
 SYMBOLS = {
@@ -90,6 +96,8 @@ SYMBOLS = {
     "gcm_get_ground": (C.c_int, [_H, C.c_void_p]),
     "gcm_grey_radiation": (C.c_int, [_H] + [C.c_double] * 4 + [_dp, _dp, C.c_void_p, C.c_void_p]),
     "gcm_solar_step": (C.c_int, [_H] + [C.c_double] * 5 + [_dp, _dp]),
+    "gcm_set_physics": (C.c_int, [_H, C.c_void_p]),
+    "gcm_get_utc": (C.c_int, [_H, _dp]),
     "gcm_snapshot": (C.c_int, [_H]),
     "gcm_restore": (C.c_int, [_H]),
     "gcm_halo_bytes": (C.c_size_t, [_H]),

@@ -53,6 +53,11 @@ class BandRunner:
         edge_first + compute_edges(stage, dt) / compute_interior(stage, dt)   GCM_PE25D phases
         mark_packed()                   the next comm_begin() waits for the work queued so far only
         steps_per_exchange, step_n(n, dt)               deep halo
+        physics_step(dt)                the column physics after the dynamics step (BASELINE configs[4]:
+                                        no_limits_2_5d.solar_timestep), own rows AND ghost rows -- the ghost
+                                        rows are radiated locally from the neighbour's own inputs, so no third
+                                        exchange per step is needed (gcm_set_physics); an engine whose library
+                                        call does the whole run (band_run) does it inside that call
     """
 
     def __init__(self, engine, rank, nranks, dist=None, north=None, south=None):
@@ -131,12 +136,19 @@ class BandRunner:
                 self.primed = True
             for stage in range(2):
                 self._finish(self.begin_stage(stage, dt))
+            self._physics(dt)
             return
         for phase in range(self.e.phases):
             reqs = self.exchange_start()
             self.e.compute_overlapped(phase, dt)      # overlaps the exchange
             self._finish(reqs)
             self.e.compute_after(phase, dt)
+        self._physics(dt)
+
+    def _physics(self, dt):
+        ps = getattr(self.e, "physics_step", None)
+        if ps is not None:
+            ps(dt)
 
     def run(self, nsteps, dt):
         """`nsteps` steps; with a deep halo the k local steps between two exchanges are one
@@ -240,6 +252,21 @@ class HipBandEngine:
 
     def band_run(self, n, dt):
         self.c.band_run(n, dt)
+
+    def set_physics(self, geom, utc=0.0):
+        """solar_timestep after every dynamics step (no_limits_2_5d.py:66-75, t_lw = 0.1, t_sw = 0.9, albedo = 0.3):
+        inside the library's gcm_band_run, or from physics_step() when the host drives the exchange"""
+        self.c.set_physics(geom, utc)
+        self._phys = [geom, float(utc)]
+
+    def physics_step(self, dt):
+        """host-driven band step: own rows and ghost rows by one gcm_solar_step on the compute stream, behind the
+        unpack of the post-corrector exchange"""
+        ph = getattr(self, "_phys", None)
+        if ph is None:
+            return
+        self.c.solar_step(ph[0], dt, ph[1])
+        ph[1] += dt
 
     def send_buffer(self, side):
         self.c.halo_pack(side, self.sbuf[side].data_ptr(), self._s(self.compute))

@@ -234,6 +234,22 @@ class Core:
         _check(lib.gcm_solar_step(self._h, float(dt), float(utc), t_lw, t_sw, albedo, _tab(lat),
                                   _tab(lon)), self._h)
 
+    def set_physics(self, geom, utc=0.0, t_lw=0.1, t_sw=0.9, albedo=0.3):
+        """every step of step() / band_run() from now on = the dynamics step followed by
+        no_limits_2_5d.solar_timestep at the handle's clock, which then advances by dt (run_model's loop,
+        no_limits_2_5d.py:229-234); geom=None switches the physics off (gcm_set_physics)"""
+        if geom is None:
+            _check(lib.gcm_set_physics(self._h, None), self._h)
+            return
+        lat, lon = self._latlon(geom)
+        ph = _lib.Physics(float(utc), t_lw, t_sw, albedo, _tab(lat), _tab(lon))
+        _check(lib.gcm_set_physics(self._h, C.byref(ph)), self._h)
+
+    def utc(self):
+        out = C.c_double()
+        _check(lib.gcm_get_utc(self._h, C.byref(out)), self._h)
+        return out.value
+
     def time_steps(self, nsteps, dt, per_kernel=True):
         ms, kms = C.c_double(), C.c_double()
         _check(lib.gcm_time_steps(self._h, int(nsteps), float(dt), C.byref(ms),

@@ -65,6 +65,12 @@ struct gcm_handle {
     bool band_overlap = false;                 // deep-halo bands: hide the exchange behind interior rows (gcm_set_band_overlap)
     hipEvent_t ev_pack = nullptr, ev_comm = nullptr;
     bool join_pending = false;                 // gcm_band_run (GCM_PE25D): work on the second stream not yet joined
+    bool on_comm = false;                      // GCM_BAND_COMM_STREAM=1 at gcm_set_exchange: exchange on the comm stream, a join per stage
+
+    // gcm_set_physics: solar_timestep as the second phase of every step
+    bool phys_on = false;
+    gcm_physics phys{};
+    std::vector<double> phys_lat, phys_lon;
 };
 
 #define HIPCHK(h, call)                                                                    \
@@ -354,6 +360,12 @@ static Sw2dArgs base_args(gcm_handle *h, double dt) {
     return a;
 }
 
+// gcm_set_physics: the radiation kernel's tables in place before a run queues anything (no-op without physics)
+static int physics_tables(gcm_handle *h) {
+    if (!h->phys_on) return GCM_OK;
+    return pe25d_physics_tables(h->pe, h->phys.t_lw, h->phys.t_sw, h->phys_lat.data(), h->phys_lon.data(), h->stream, &h->err);
+}
+
 // what the launches queued since the last check returned: the status hipLaunchKernel handed back for the
 // fused step (kept in the handle: step_rows has many callers) and the runtime's sticky last error
 static int launch_status(gcm_handle *h) {
@@ -455,9 +467,17 @@ int gcm_step(gcm_handle *h, int nsteps, double dt) {
     if (!h || nsteps < 0) return GCM_ERR_ARG;
     if (h->cfg.device >= 0) HIPCHK(h, hipSetDevice(h->cfg.device));
     if (h->pe) {
+        int rc = physics_tables(h);
+        if (rc) return rc;
         for (int n = 0; n < nsteps; ++n) {
-            int rc = pe25d_step(h->pe, dt, h->stream, &h->err);
-            if (rc) return rc;
+            if ((rc = pe25d_step(h->pe, dt, h->stream, &h->err))) return rc;
+            if (h->phys_on) {
+                // no_limits_2_5d.py:229-234 with the physics below full_timestep's early return (:96): the dynamics
+                // step, then solar_timestep at the current utc, then utc += dt
+                if ((rc = pe25d_solar_rows(h->pe, -1, 0, h->H, 0, 0, false, dt, h->phys.utc, h->phys.albedo, h->stream, &h->err)))
+                    return rc;
+                h->phys.utc += dt;
+            }
         }
         return GCM_OK;
     }
@@ -698,6 +718,10 @@ int gcm_set_exchange(gcm_handle *h, const gcm_exchange *x) {
     h->xch_set = true;
     h->primed = false;
     if (const char *e = getenv("GCM_BAND_OVERLAP")) h->band_overlap = e[0] == '1';
+    {
+        const char *e = getenv("GCM_BAND_COMM_STREAM");     // diagnostic: the exchange on the comm stream, a join per stage (round 1)
+        h->on_comm = e && e[0] == '1';
+    }
     // GCM_PE25D: the edge rows of a stage are updated and packed into the send buffers on the
     // handle's second stream (gcm_set_halo_buffers)
     if (h->pe) return pe25d_set_halo_buffers(h->pe, x->send_north, x->send_south, h->stream, &h->err);
@@ -763,16 +787,26 @@ static int band_pack_exchange(gcm_handle *h) {
 // reads ghost rows -- the next stage's K1, column sums, edge rows -- is queued on the second stream, behind
 // the unpack, in stream order.  gcm_band_run joins the two streams once, when it returns.
 // GCM_BAND_COMM_STREAM=1: the exchange on the comm stream and a join per stage, as in round 1.
+// With gcm_set_physics the step has a second phase, solar_timestep (no_limits_2_5d.py:66-75), which changes theta and
+// the ground temperature in place AFTER the post-corrector exchange has left: the ghost rows are radiated locally
+// (column-local kernel, the neighbour's own inputs -- theta and p as the exchange delivered them, the ground
+// temperature's ghost rows, the latitude of the global row -- hence the neighbour's own bits), on the second stream
+// right behind the unpack and ahead of the ghost rows' column sums and anchors; the band's own rows follow the
+// corrector on the compute stream, which by then has waited for the edge rows and their pack.
 static int band_step_pe(gcm_handle *h, double dt) {
     int rc = GCM_OK;
-    static const bool on_comm = getenv("GCM_BAND_COMM_STREAM") && getenv("GCM_BAND_COMM_STREAM")[0] == '1';
-    hipStream_t ax = on_comm ? nullptr : pe25d_aux_stream(h->pe);
+    hipStream_t ax = h->on_comm ? nullptr : pe25d_aux_stream(h->pe);
+    const int H = h->H;
     for (int stage = 0; stage < 2; ++stage) {
         if ((rc = pe25d_step_phase(h->pe, 2 * stage, dt, h->stream, &h->err))) return rc;
         if (ax) {
             if ((rc = band_post(h, false, ax))) return rc;
             if ((rc = gcm_halo_unpack2(h, h->xch.recv_north, h->xch.recv_south, ax))) return rc;
-            pe25d_prep_ghost_rows(h->pe);
+            if (stage == 1 && h->phys_on &&
+                (rc = pe25d_solar_rows(h->pe, pe25d_new_state_set(h->pe), -kGhost, 0, H, H + kGhost, true, dt, h->phys.utc,
+                                       h->phys.albedo, ax, &h->err)))
+                return rc;
+            if ((rc = pe25d_prep_ghost_rows(h->pe, &h->err))) return rc;
             h->join_pending = true;
         }
         if ((rc = pe25d_step_phase(h->pe, 2 * stage + 1, dt, h->stream, &h->err))) return rc;
@@ -780,6 +814,13 @@ static int band_step_pe(gcm_handle *h, double dt) {
             if ((rc = pe25d_wait_edges(h->pe, h->comm, &h->err))) return rc;
             if ((rc = band_exchange(h))) return rc;
         }
+    }
+    if (h->phys_on) {
+        // own rows (and, when the exchange was joined into the compute stream, the ghost rows with them)
+        const int g = ax ? 0 : kGhost;
+        if ((rc = pe25d_solar_rows(h->pe, -1, -g, H + g, 0, 0, ax != nullptr, dt, h->phys.utc, h->phys.albedo, h->stream, &h->err)))
+            return rc;
+        h->phys.utc += dt;
     }
     return GCM_OK;
 }
@@ -800,7 +841,8 @@ int gcm_band_run(gcm_handle *h, int nsteps, double dt) {
     if (h->cfg.device >= 0) HIPCHK(h, hipSetDevice(h->cfg.device));
     int rc = GCM_OK;
     if (h->pe) {
-        if (!h->primed) {                                  // ghost rows of the initial state, once
+        if ((rc = physics_tables(h))) return rc;
+        if (!h->primed) {                                  // ghost rows of the initial state (and of the ground temperature), once
             if ((rc = band_pack_exchange(h))) return rc;
             h->primed = true;
         }
@@ -1102,7 +1144,31 @@ int gcm_stats(gcm_handle *h, const double *area, int area_len, double *out9) {
 int gcm_set_ground(gcm_handle *h, const double *gt) {
     if (!h || !gt) return GCM_ERR_ARG;
     if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_set_ground: GCM_PE25D only");
+    h->primed = false;                                     // gcm_band_run: the ghost rows of the ground temperature travel again
     return pe25d_ground(h->pe, true, gt, nullptr, h->stream, &h->err);
+}
+
+int gcm_set_physics(gcm_handle *h, const gcm_physics *ph) {
+    if (!h) return GCM_ERR_ARG;
+    if (!h->pe) return fail(h, GCM_ERR_UNSUPPORTED, "gcm_set_physics: GCM_PE25D only");
+    if (!ph) {
+        h->phys_on = false;
+        return GCM_OK;
+    }
+    if (!ph->lat || !ph->lon) return fail(h, GCM_ERR_ARG, "gcm_set_physics: lat and lon tables are required");
+    h->phys = *ph;
+    h->phys_lat.assign(ph->lat, ph->lat + h->cfg.global_height);
+    h->phys_lon.assign(ph->lon, ph->lon + h->W);
+    h->phys.lat = h->phys.lon = nullptr;                   // (the copies above are what is used)
+    h->phys_on = true;
+    return GCM_OK;
+}
+
+int gcm_get_utc(gcm_handle *h, double *utc) {
+    if (!h || !utc) return GCM_ERR_ARG;
+    if (!h->phys_on) return fail(h, GCM_ERR_STATE, "gcm_get_utc: no physics registered (gcm_set_physics)");
+    *utc = h->phys.utc;
+    return GCM_OK;
 }
 
 int gcm_polar_filter(gcm_handle *h, int nlev, const double *in, double *out) {

@@ -64,8 +64,6 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
     const int nseg = a.nseg;
     const int na = a.j1 - a.j0, nb = a.jb1 - a.jb0;
     const int ga = (na + R - 1) / R, gb = (nb + R - 1) / R;
-    const int per_xcd = gridDim.x / 8;                           // = rs_per_xcd * ncol (launch)
-    const int rs_per_xcd = per_xcd / ncol;
     const int l = blockIdx.x / 8;
     const int rsl = l / ncol;
     const int ct = l - rsl * ncol;

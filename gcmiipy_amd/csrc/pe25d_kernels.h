@@ -24,7 +24,7 @@ int pe25d_step_part(Pe25d *m, int part, double dt, hipStream_t s, std::string *e
 int pe25d_step_phase(Pe25d *m, int phase, double dt, hipStream_t s, std::string *err);
 int pe25d_set_halo_buffers(Pe25d *m, void *north, void *south, hipStream_t s, std::string *err);
 int pe25d_wait_edges(Pe25d *m, hipStream_t s, std::string *err);
-void pe25d_prep_ghost_rows(Pe25d *m);       // gcm_band_run: behind the unpack on the second stream
+int pe25d_prep_ghost_rows(Pe25d *m, std::string *err);   // gcm_band_run: behind the unpack on the second stream
 hipStream_t pe25d_aux_stream(const Pe25d *m);
 // a new non-blocking stream that demonstrably runs beside `main` (and `other`, may be null)
 hipStream_t concurrent_stream(hipStream_t main, hipStream_t other);
@@ -37,6 +37,11 @@ int pe25d_filter_field(Pe25d *m, int nlev, const double *in, double *out, hipStr
 int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, double t_sw, double albedo,
                     const double *lat, const double *lon, double *dTdt_host, double *dtg_host,
                     hipStream_t s, std::string *err);
+int pe25d_physics_tables(Pe25d *m, double t_lw, double t_sw, const double *lat, const double *lon, hipStream_t s,
+                         std::string *err);
+int pe25d_solar_rows(Pe25d *m, int set, int j0, int j1, int jb0, int jb1, bool keep_ghosts, double dt, double utc, double albedo,
+                     hipStream_t s, std::string *err);
+int pe25d_new_state_set(const Pe25d *m);    // the set a corrector stage in flight writes (before the swap), else the current one
 int pe25d_stats(Pe25d *m, const double *area_host, int area_len, double out[9], hipStream_t s, std::string *err);
 int pe25d_filter_plan(int n, unsigned *out, int cap);   // gcm_filter_plan
 void pe25d_tv_shape(const Pe25d *m, int field, long *n_outer, long *n_axis, long *n_inner, int *wrap);

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
     T ex_k = exner(spc * a.sig[0] + a.ptop, tab);
     const T t0 = t_k, ex0 = ex_k;                       // level 0, for the k wrap at the top
     T acc = T(0.0);
-#pragma unroll(LMAX > 0 ? LMAX : 6)
+    constexpr int kUnrollA = LMAX > 0 ? LMAX : 6, kUnrollB = LMAX > 0 ? LMAX : 1;
+#pragma unroll kUnrollA
     for (int k = 0; k < (LMAX > 0 ? LMAX : L); ++k) {
         if (LMAX > 0 && k >= L) break;
         const T tp = spc * a.sig[k] + a.ptop;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
     }
     T run = acc + hmG;                                  // stp_n[0], dynamics.py:132
     a.phi[c3 + i] = run;
-#pragma unroll(LMAX > 0 ? LMAX : 1)
+#pragma unroll kUnrollB
     for (int k = 1; k < (LMAX > 0 ? LMAX : L); ++k) {        // phi = cumsum(stp_n), stp_n = km(stp)
         if (LMAX > 0 && k >= L) break;
         run = add_rn(run, LMAX > 0 ? stp_reg[k - 1] : pk[(k - 1) * kColThreads]);
@@ -315,6 +316,8 @@ struct RadArgsT {
     T *dTdt, *dtg;                                           // tendencies out of the diagnostic form (3-D, 2-D scratch)
     double hour_angle, albedo, dt;
     int apply;                                               // 1: t, gt updated in place
+    int j0, n0, jb0;                                         // rows of the launch: [j0, j0 + n0), then from jb0 on (a band's ghost
+                                                             // rows on either side in one launch: negative / >= H)
 };
 
 // The arithmetic is float64 for either storage type T: the column physics is a small share of a
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(kRadThreads) void pe_radiation_kernel(PeArgsT<T> a,
     double *p_lwb = (double *)rad_park_raw + threadIdx.x;
     double lwb_reg[LMAX > 0 ? LMAX : 1];
     const int i = blockIdx.x * kRadThreads + threadIdx.x;
-    const int j = blockIdx.y;
+    const int j = (int)blockIdx.y < r.n0 ? r.j0 + (int)blockIdx.y : r.jb0 + ((int)blockIdx.y - r.n0);
     if (i >= W) return;
     const int jg = wrapi(a.row0 + j, a.Hg);
     const long c3 = (long)j * L * W + i, c2 = (long)j * W + i;
@@ -390,7 +393,8 @@ __global__ __launch_bounds__(kRadThreads) void pe_radiation_kernel(PeArgsT<T> a,
         return (1 - tlw(k)) * kSb * (t2 * t2);
     };
     double B = 0.0, up = 0.0;
-#pragma unroll(LMAX > 0 ? LMAX : 2)
+    constexpr int kUnroll = LMAX > 0 ? LMAX : 2;
+#pragma unroll kUnroll
     for (int k = 0; k < (LMAX > 0 ? LMAX : L); ++k) {       // bottom-up: emission, B, LWA_b
         if (LMAX > 0 && k >= L) break;
         double tt;
@@ -405,7 +409,7 @@ __global__ __launch_bounds__(kRadThreads) void pe_radiation_kernel(PeArgsT<T> a,
     if (r.apply) r.gt[c2] = gt + dtg * r.dt;
     else r.dtg[c2] = (T)dtg;
     double down = 0.0;
-#pragma unroll(LMAX > 0 ? LMAX : 2)
+#pragma unroll kUnroll
     for (int kk = 0; kk < (LMAX > 0 ? LMAX : L); ++kk) {     // top-down: LWA_a, then eq. 2.34
         const int k = (LMAX > 0 ? LMAX : L) - 1 - kk;
         if (LMAX > 0 && k >= L) continue;
@@ -483,6 +487,7 @@ struct Pe25d {
     int cus = 256;
     int last_stage_set = -1;                    // state set the last half step took its stage state from (gcm_get_intermediate)
     int ghost_ready = -1;                       // state set whose ghost rows' column sums and anchors are queued already (pe25d_prep_ghost_rows)
+    int last_unpack_set = -1;                   // state set whose ghost rows the last unpack filled (halo_t)
     bool pit2d = true;                          // pit from the column sums K4 leaves (nseg == 1, row-group K4)
     int nseg_edge = 1;                          // bands: level segments of the EDGE rows' K4 launch (see half_t)
     bool cs_valid[3] = {false, false, false};   // the state set's column sums belong to its winds
@@ -491,7 +496,8 @@ struct Pe25d {
     double *exner_tab = nullptr;
     FftPlan plan{};
     SuperPlan cplan{};
-    double *gt = nullptr;                       // ground temperature [H][W] (column physics)
+    double *gt = nullptr;                       // ground temperature [H + 2 ghost rows a side][W], interior row 0 (column physics)
+    bool gt_set = false;                        // gcm_set_ground was called
     double *stats_dev = nullptr;                // gcm_stats: block partials, then the area table
     std::vector<double> stats_host, area_host;
     double *rad_tab = nullptr;                  // 5 x [L] level tables of the last radiation call
@@ -708,6 +714,7 @@ hipStream_t concurrent_stream(hipStream_t main, hipStream_t other) {
 }
 
 hipStream_t pe25d_aux_stream(const Pe25d *m) { return m->aux; }
+int pe25d_new_state_set(const Pe25d *m) { return (m->pack_set >= 0 && m->pack_set != 2) ? m->pack_set : m->cur_i; }
 
 Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string *err) {
     if (!cfg.dx_j || !cfg.dx_h || !cfg.sig || !cfg.dsig || !cfg.sigb || !cfg.sigt) {
@@ -795,6 +802,12 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
     double tab[kExnerTabDoubles];
     build_exner_table(tab);
     if (!dev_upload(m, &m->exner_tab, tab, kExnerTabDoubles)) return bad("exner table");
+    {
+        // ground temperature (column physics), with a band's ghost rows: they travel with every ghost-row message
+        double *d = nullptr;
+        if (!dev_upload<double>(m, &d, nullptr, rows_alloc(m) * (size_t)W)) return bad("ground temperature");
+        m->gt = d + (size_t)kGhost * W;
+    }
     const char *no_aux = getenv("GCM_PE_SINGLE_STREAM");      // diagnostic: one chain, one stream
     // a plain stream: a high-priority one finished the edge rows earlier, but in some processes
     // (depending on how many streams existed before) the whole step then ran at half speed
@@ -866,6 +879,7 @@ int pe25d_set(Pe25d *m, bool star, const double *p, const double *u, const doubl
     int rc = xfer(m, star ? 2 : m->cur_i, true, in, nullptr, s, err);
     if (u || v) m->cs_valid[star ? 2 : m->cur_i] = false;
     m->ghost_ready = -1;
+    m->last_stage_set = -1;                      // gcm_get_intermediate: the stage state the anchors belong to is gone
     if (rc == GCM_OK) m->star_valid = star;
     return rc;
 }
@@ -1146,12 +1160,18 @@ static void half(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1
 // the state the NEXT stage reads; their column sums and the south ghost row's geopotential depend on nothing
 // else, so they are queued here -- beside the interior rows' K4 of the stage still running -- instead of at the
 // head of the next stage's chain B, where they were 17 us in front of K1.
-void pe25d_prep_ghost_rows(Pe25d *m) {
-    if (m->wrap || !m->aux) return;
+int pe25d_prep_ghost_rows(Pe25d *m, std::string *err) {
+    if (m->wrap || !m->aux) return GCM_OK;
     int set = m->star_valid ? 2 : m->cur_i;                      // the set the unpack has just filled (halo_t)
     if (m->pack_set >= 0 && m->pack_set != 2) set = m->pack_set;
+    if (set != m->last_unpack_set) {
+        // the two functions pick the set by the same rule; if they ever disagree the next stage would take its
+        // ghost rows' column sums and anchors from rows nobody filled
+        *err = "gcm_band_run: the ghost rows just unpacked are not those of the state the next stage reads";
+        return GCM_ERR_STATE;
+    }
     const bool p2 = m->pit2d && m->nseg == 1;
-    if (p2 && !m->cs_valid[set]) return;                         // (a fresh state: the stage does all rows itself)
+    if (p2 && !m->cs_valid[set]) return GCM_OK;                  // (a fresh state: the stage does all rows itself)
     if (m->f32) {
         PeArgsT<float> a = make_args<float>(m, set, set, 0.0);
         a.j0 = 0; a.j1 = m->H + 1;
@@ -1162,6 +1182,7 @@ void pe25d_prep_ghost_rows(Pe25d *m) {
         prep_rows<double>(m, a, set, p2, m->H, 1, m->aux);
     }
     m->ghost_ready = set;
+    return GCM_OK;
 }
 
 int pe25d_half(Pe25d *m, int stage, double dt, hipStream_t s, std::string *err) {
@@ -1300,7 +1321,9 @@ int pe25d_wait_edges(Pe25d *m, hipStream_t s, std::string *err) {
 // ghost rows: [p: 2 rows][u,v,t,q: 2 rows x L levels]; contiguous in the device layout.
 // Which state is exchanged follows the step phase: the predicted state once it exists.
 size_t pe25d_halo_bytes(const Pe25d *m) {
-    return (m->f32 ? sizeof(float) : sizeof(double)) * (size_t)kGhost * m->W * (1 + 4 * (size_t)m->L);
+    // (+ the ground temperature's two rows, float64 for either storage type: gcm_set_physics)
+    return (m->f32 ? sizeof(float) : sizeof(double)) * (size_t)kGhost * m->W * (1 + 4 * (size_t)m->L) +
+           sizeof(double) * (size_t)kGhost * m->W;
 }
 
 template <typename T>
@@ -1311,6 +1334,7 @@ static void halo_t(Pe25d *m, bool pack, int side, void *dev_buf, SegCopy *c) {
     int set = m->star_valid ? 2 : m->cur_i;
     if (pack && m->pack_set >= 0) set = m->pack_set;
     if (!pack && m->pack_set >= 0 && m->pack_set != 2) set = m->pack_set;   // new-state ghosts arrive before the swap
+    if (!pack) m->last_unpack_set = set;
     T *b = (T *)dev_buf;
     for (int f = 0; f < GCM_NFIELDS; ++f) {
         const size_t per_row = (size_t)m->W * (f == GCM_P ? 1 : m->L);
@@ -1323,6 +1347,18 @@ static void halo_t(Pe25d *m, bool pack, int side, void *dev_buf, SegCopy *c) {
         c->dst[c->nseg] = (double *)(pack ? b : ghost);
         c->n[c->nseg++] = n * (long)sizeof(T) / 8;
         b += n;
+    }
+    // the ground temperature: one array for all state sets, advanced by the column physics only.  A band's
+    // ghost rows of it are radiated locally (pe25d_solar_rows), so what a message carries equals what the
+    // ghost rows hold already -- except in the first exchange after gcm_set_ground, which is what it is for.
+    {
+        double *gb = (double *)b;                 // (2 rows x even W floats: a whole number of 8-byte words)
+        const size_t n2 = (size_t)kGhost * m->W;
+        double *edge = side == 0 ? m->gt : m->gt + (size_t)(m->H - kGhost) * m->W;
+        double *ghost = side == 0 ? m->gt - n2 : m->gt + (size_t)m->H * m->W;
+        c->src[c->nseg] = pack ? edge : gb;
+        c->dst[c->nseg] = pack ? gb : ghost;
+        c->n[c->nseg++] = (long)n2;
     }
 }
 
@@ -1349,6 +1385,7 @@ static int filter_field_t(Pe25d *m, int nlev, const double *in, double *out, hip
     PeBufs<T> &B = bufs<T>(m);
     const int W = m->W, H = m->H;
     const size_t bytes = sizeof(double) * (size_t)nlev * H * W;
+    m->last_stage_set = -1;                      // spu, pgfu and pit are scratch here: the parity tap has nothing to return
     hipError_t e = hipMemcpyAsync(m->stage3, in, bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(pe_to_device_kernel<T>, dim3(1024), dim3(256), 0, s, B.pgfu, m->stage3, W, H, nlev);
@@ -1454,29 +1491,29 @@ int pe25d_filter_field(Pe25d *m, int nlev, const double *in, double *out, hipStr
 
 int pe25d_ground(Pe25d *m, bool set, const double *in, double *out, hipStream_t s, std::string *err) {
     const size_t bytes = sizeof(double) * (size_t)m->H * m->W;
-    if (!m->gt) {
-        void *d = nullptr;
-        if (hipMalloc(&d, bytes) != hipSuccess || hipMemsetAsync(d, 0, bytes, s) != hipSuccess) {
-            *err = "hip: ground temperature allocation failed";
-            return GCM_ERR_HIP;
-        }
-        m->allocs.push_back(d);
-        m->gt = (double *)d;
-    }
     hipError_t e = set ? hipMemcpyAsync(m->gt, in, bytes, hipMemcpyHostToDevice, s)
                        : hipMemcpyAsync(out, m->gt, bytes, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { *err = "hip: ground temperature transfer failed"; return GCM_ERR_HIP; }
+    if (set) m->gt_set = true;
     return GCM_OK;
 }
 
+// rows [j0, j1) and [jb0, jb1) of state set `set` (a band's ghost rows: negative, or >= H); keep_ghosts: the caller
+// radiates the ghost rows itself before their column sums and anchors are queued (gcm_band_run), so what
+// pe25d_prep_ghost_rows left stays valid
 template <typename T>
-static int radiation_launch(Pe25d *m, bool apply, double dt, double hour_angle, double albedo,
-                            double *dTdt_host, double *dtg_host, hipStream_t s, std::string *err) {
+static int radiation_launch(Pe25d *m, int set, int j0, int j1, int jb0, int jb1, bool keep_ghosts, bool apply, double dt,
+                            double hour_angle, double albedo, double *dTdt_host, double *dtg_host, hipStream_t s,
+                            std::string *err) {
     PeBufs<T> &B = bufs<T>(m);
     const int W = m->W, H = m->H, L = m->L, Hg = m->Hg;
-    PeArgsT<T> a = make_args<T>(m, m->cur_i, m->cur_i, dt);
+    const int nrows = std::max(0, j1 - j0) + std::max(0, jb1 - jb0);
+    if (nrows <= 0) return GCM_OK;
+    PeArgsT<T> a = make_args<T>(m, set, set, dt);
+    a.p = B.st[set][GCM_P];                               // (make_args takes the base state from the current set)
     RadArgsT<T> r{};
+    r.j0 = j0; r.n0 = std::max(0, j1 - j0); r.jb0 = jb0;
     r.tlw = m->rad_tab; r.tsw = r.tlw + L; r.csw_top = r.tsw + L; r.clw_b_div = r.csw_top + L; r.swfac = r.clw_b_div + L;
     r.sigk = r.swfac + L;
     r.coslat = m->rad_geo; r.sinlat = m->rad_geo + Hg; r.lon = m->rad_geo + 2 * Hg;
@@ -1484,10 +1521,11 @@ static int radiation_launch(Pe25d *m, bool apply, double dt, double hour_angle, 
     r.dTdt = B.pgfu; r.dtg = B.pit;
     r.hour_angle = hour_angle;
     r.albedo = albedo; r.dt = dt; r.apply = apply ? 1 : 0;
-    if (apply) m->ghost_ready = -1;                        // theta changes in place
+    if (apply && !keep_ghosts) m->ghost_ready = -1;        // theta changes in place
+    m->last_stage_set = -1;                                // gcm_get_intermediate: theta changed, or pgfu / pit hold the tendencies
     {
-        const dim3 gg((W + kRadThreads - 1) / kRadThreads, H);
-        T *th = B.st[m->cur_i][GCM_T];
+        const dim3 gg((W + kRadThreads - 1) / kRadThreads, nrows);
+        T *th = B.st[set][GCM_T];
         static const bool generic = getenv("GCM_PE_RAD_GENERIC") != nullptr;     // diagnostic: the LDS-parked form
         const bool fact = m->cfg.ptop == 0.0 && r.sigk != nullptr;
         if (L <= 24 && !generic && fact) hipLaunchKernelGGL((pe_radiation_kernel<T, 24, true>), gg, dim3(kRadThreads), 0, s, a, r, th);
@@ -1516,13 +1554,13 @@ static int radiation_launch(Pe25d *m, bool apply, double dt, double hour_angle, 
     return GCM_OK;
 }
 
-// basic_grey_radiation (+ optional in-place solar_timestep).  dTdt_host / dtg_host may be null.
-int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, double t_sw, double albedo,
-                    const double *lat, const double *lon, double *dTdt_host, double *dtg_host,
-                    hipStream_t s, std::string *err) {
-    if (!m->gt) { *err = "radiation: set the ground temperature first (gcm_set_ground)"; return GCM_ERR_STATE; }
+// the level tables (t_lw, t_sw) and the lat / lon tables of the radiation kernel, uploaded when they change
+int pe25d_physics_tables(Pe25d *m, double t_lw, double t_sw, const double *lat, const double *lon, hipStream_t s,
+                         std::string *err) {
+    if (!m->gt_set) { *err = "radiation: set the ground temperature first (gcm_set_ground)"; return GCM_ERR_STATE; }
     if (!lat || !lon) { *err = "radiation: lat and lon tables are required"; return GCM_ERR_ARG; }
     const int W = m->W, L = m->L, Hg = m->Hg;
+    bool uploaded = false;
     if (m->rad_key[0] != t_lw || m->rad_key[1] != t_sw || !m->rad_tab) {
         // level tables, same expression order as grey_solar.py:323-333,377-385,541
         std::vector<double> &T = m->rad_tab_host;
@@ -1548,6 +1586,7 @@ int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, do
             *err = "hip: radiation table upload failed"; return GCM_ERR_HIP;
         }
         m->rad_key[0] = t_lw; m->rad_key[1] = t_sw;
+        uploaded = true;
     }
     // lat / lon tables: uploaded when their content changes (normally once)
     if (m->rad_latlon.size() != (size_t)Hg + W || memcmp(m->rad_latlon.data(), lat, sizeof(double) * Hg) ||
@@ -1565,10 +1604,35 @@ int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, do
         if (hipMemcpyAsync(m->rad_geo, Gt.data(), sizeof(double) * Gt.size(), hipMemcpyHostToDevice, s) != hipSuccess) {
             *err = "hip: radiation geometry upload failed"; return GCM_ERR_HIP;
         }
+        uploaded = true;
     }
+    // (a band radiates its ghost rows on the second stream: the tables are in place before anything is queued there)
+    if (uploaded && hipStreamSynchronize(s) != hipSuccess) { *err = "hip: radiation table upload failed"; return GCM_ERR_HIP; }
+    return GCM_OK;
+}
+
+// solar_timestep (no_limits_2_5d.py:66-75) of rows [j0, j1) and [jb0, jb1) of state set `set` (-1: the current one) on stream `s`;
+// the tables must be in place (pe25d_physics_tables)
+int pe25d_solar_rows(Pe25d *m, int set, int j0, int j1, int jb0, int jb1, bool keep_ghosts, double dt, double utc, double albedo,
+                     hipStream_t s, std::string *err) {
+    if (set < 0) set = m->cur_i;
     const double hour_angle = utc / (-24 * 3600.0) * 360 * (M_PI / 180);      // grey_solar.py:51
-    return m->f32 ? radiation_launch<float>(m, apply, dt, hour_angle, albedo, dTdt_host, dtg_host, s, err)
-                  : radiation_launch<double>(m, apply, dt, hour_angle, albedo, dTdt_host, dtg_host, s, err);
+    return m->f32 ? radiation_launch<float>(m, set, j0, j1, jb0, jb1, keep_ghosts, true, dt, hour_angle, albedo, nullptr, nullptr, s, err)
+                  : radiation_launch<double>(m, set, j0, j1, jb0, jb1, keep_ghosts, true, dt, hour_angle, albedo, nullptr, nullptr, s, err);
+}
+
+// basic_grey_radiation (+ optional in-place solar_timestep).  dTdt_host / dtg_host may be null.  On a latitude
+// band the in-place form advances the ghost rows too (their theta as the post-corrector exchange delivered it,
+// their ground temperature as the last message delivered it): the neighbour's own inputs, the neighbour's own bits.
+int pe25d_radiation(Pe25d *m, bool apply, double dt, double utc, double t_lw, double t_sw, double albedo,
+                    const double *lat, const double *lon, double *dTdt_host, double *dtg_host,
+                    hipStream_t s, std::string *err) {
+    int rc = pe25d_physics_tables(m, t_lw, t_sw, lat, lon, s, err);
+    if (rc) return rc;
+    const double hour_angle = utc / (-24 * 3600.0) * 360 * (M_PI / 180);      // grey_solar.py:51
+    const int g = (apply && !m->wrap) ? kGhost : 0;
+    return m->f32 ? radiation_launch<float>(m, m->cur_i, -g, m->H + g, 0, 0, false, apply, dt, hour_angle, albedo, dTdt_host, dtg_host, s, err)
+                  : radiation_launch<double>(m, m->cur_i, -g, m->H + g, 0, 0, false, apply, dt, hour_angle, albedo, dTdt_host, dtg_host, s, err);
 }
 
 // calc_energy + STATS in one launch and one synchronisation of `s`: out9 = u_max, u_min, v_max,

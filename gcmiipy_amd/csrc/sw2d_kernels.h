@@ -49,10 +49,10 @@ void build_exner_table(double *tab);
 void launch_copy_rows(double *dst, const double *src, int W, int nrows, hipStream_t s);
 
 // up to 5 contiguous segments copied by ONE launch (ghost-row pack / unpack of all fields)
-struct SegCopy {          // up to 5 fields x 2 sides in one launch
-    double *dst[10];
-    const double *src[10];
-    long n[10];
+struct SegCopy {          // up to (5 fields + the ground temperature) x 2 sides in one launch
+    double *dst[12];
+    const double *src[12];
+    long n[12];
     int nseg;
 };
 void launch_seg_copy(const SegCopy &c, hipStream_t s);

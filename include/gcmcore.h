@@ -215,6 +215,25 @@ int gcm_grey_radiation(gcm_handle *h, double utc, double t_lw, double t_sw, doub
                        const double *lat, const double *lon, double *dTdt, double *dt_ground);
 int gcm_solar_step(gcm_handle *h, double dt, double utc, double t_lw, double t_sw, double albedo,
                    const double *lat, const double *lon);
+/* The column physics as the second phase of every step (BASELINE configs[4]: dynamics + solar_timestep;
+ * the loop of no_limits_2_5d.run_model, :229-234, with the physics the reference keeps below
+ * full_timestep's early return, :94-96).  After gcm_set_physics every step taken by gcm_step and
+ * gcm_band_run is  matsuno_timestep(dt)  followed by  solar_timestep(t, p, g, dt, utc, geom)  and
+ * utc += dt  (:231).  On a latitude band (nranks > 1) the ghost rows are radiated LOCALLY -- the kernel
+ * is column-local, so no third exchange per step is needed: the ghost rows of the ground temperature
+ * travel with every ghost-row message (gcm_halo_bytes counts them; pack / unpack move them), the ghost
+ * rows of theta that the post-corrector exchange delivers are advanced by the same kernel with the
+ * neighbour's own inputs, and so hold the neighbour's own bits.  An explicit gcm_solar_step on a band
+ * does the same (own rows and ghost rows), for callers that drive the exchange themselves; the ghost
+ * rows of the current state must then be current (the post-corrector exchange unpacked).
+ * `lat` [global_height] and `lon` [width] are copied.  NULL switches the physics off.          */
+typedef struct {
+    double utc;                  /* seconds; advanced by dt after every step                  */
+    double t_lw, t_sw, albedo;   /* the reference passes 0.1, 0.9, 0.3  no_limits_2_5d.py:69  */
+    const double *lat, *lon;     /* geom.lat [global_height], geom.long [width], radians      */
+} gcm_physics;
+int gcm_set_physics(gcm_handle *h, const gcm_physics *ph);
+int gcm_get_utc(gcm_handle *h, double *utc);   /* the physics clock (GCM_ERR_STATE without gcm_set_physics) */
 
 /* Device-side snapshot / restore of the current state, ghost rows included (2-D models): a long
  * run can restart from a known state without a host round trip.  gcm_restore is asynchronous on

@@ -6,7 +6,7 @@ ghost rows, which are discarded).  The product's engine is HipBandEngine."""
 import numpy as np
 import torch
 
-from oracle import sw2d, sw2d_temp, tracer, dynamics, geometry as ogeo
+from oracle import sw2d, sw2d_temp, tracer, dynamics, physics, geometry as ogeo
 
 G = 2  # ghost rows per side
 
@@ -94,6 +94,7 @@ def band_geom(global_geom, row0, nrows):
     g.dx_h = global_geom.dx_h[:, rows, :]
     g.dy, g.ptop = global_geom.dy, global_geom.ptop
     g.heightmap = global_geom.heightmap[rows]
+    g.lat, g.long = global_geom.lat[rows], global_geom.long        # (the column physics)
     return g
 
 
@@ -102,8 +103,14 @@ class NumpyBandPE:
     current one before the predictor and the predicted one before the corrector."""
     phases = 2
 
-    def __init__(self, p, u, v, t, q, global_geom, row0, edge_first=False):
+    def __init__(self, p, u, v, t, q, global_geom, row0, edge_first=False, gt=None, utc=0.0):
+        """gt (the band's rows of the ground temperature) switches the column physics on: after every dynamics step
+        solar_timestep (no_limits_2_5d.py:66-75) on the band's own rows AND its ghost rows -- the ghost rows of theta as
+        the post-corrector exchange delivered them, those of gt as they travelled with the messages; no third
+        exchange per step"""
         self.edge_first = edge_first
+        self.gt = None if gt is None else np.pad(gt, ((G, G), (0, 0)))
+        self.utc = utc
         self.pending = None
         self.H = p.shape[0]
         self.row0, self.Hg = row0, global_geom.height
@@ -142,20 +149,31 @@ class NumpyBandPE:
     def _rows(a, rows):
         return a[rows] if a.ndim == 2 else a[:, rows]
 
+    def _xarrays(self):
+        return list(self._xstate()) + ([self.gt] if self.gt is not None else [])
+
     def send_buffer(self, side):
         rows = slice(G, 2 * G) if side == 0 else slice(self.H, self.H + G)
-        return torch.from_numpy(np.concatenate([self._rows(a, rows).ravel() for a in self._xstate()]))
+        return torch.from_numpy(np.concatenate([self._rows(a, rows).ravel() for a in self._xarrays()]))
 
     def recv_buffer(self, side):
-        n = sum(self._rows(a, slice(0, G)).size for a in self.cur)
+        n = sum(self._rows(a, slice(0, G)).size for a in self._xarrays())
         self.rb[side] = torch.empty(n, dtype=torch.float64)
         return self.rb[side]
+
+    def physics_step(self, dt):
+        if self.gt is None:
+            return
+        t_n, gt_n = physics.solar_timestep(self.cur[3], self.cur[0], self.gt, dt, self.utc, self.geom)
+        self.cur[3][...] = t_n
+        self.gt[...] = gt_n
+        self.utc += dt
 
     def unpack(self, side):
         buf = self.rb[side].numpy()
         rows = slice(0, G) if side == 0 else slice(self.H + G, self.H + 2 * G)
         off = 0
-        for a in self._xstate():
+        for a in self._xarrays():
             tgt = self._rows(a, rows)
             n = tgt.size
             if a.ndim == 2:
@@ -198,4 +216,4 @@ class NumpyBandPE:
         raise AssertionError("not used with nranks > 1")
 
     def interior_state(self):
-        return [self._rows(a, slice(G, self.H + G)).copy() for a in self.cur]
+        return [self._rows(a, slice(G, self.H + G)).copy() for a in self.cur + ([self.gt] if self.gt is not None else [])]

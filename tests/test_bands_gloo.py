@@ -59,7 +59,7 @@ def _worker_2d(rank, world, port, shape, temp, steps, outdir, halo_steps=1):
     dist.destroy_process_group()
 
 
-def _worker_pe(rank, world, port, hwl, steps, outdir, edge_first=False):
+def _worker_pe(rank, world, port, hwl, steps, outdir, edge_first=False, phys=False):
     from band_engines import NumpyBandPE
     from gcmiipy_amd.bands import BandRunner, split_rows
     from oracle import geometry as ogeo
@@ -71,12 +71,13 @@ def _worker_pe(rank, world, port, hwl, steps, outdir, edge_first=False):
     p, u, v, t, q = _ic_pe(geom)
     row0, n = split_rows(H, world)[rank]
     sl = slice(row0, row0 + n)
-    eng = NumpyBandPE(p[sl], u[:, sl], v[:, sl], t[:, sl], q[:, sl], geom, row0, edge_first)
+    gt = _ic_gt(geom)[sl] if phys else None
+    eng = NumpyBandPE(p[sl], u[:, sl], v[:, sl], t[:, sl], q[:, sl], geom, row0, edge_first, gt=gt, utc=UTC0)
     runner = BandRunner(eng, rank, world, dist)
     for _ in range(steps):
         runner.step(120.0)
     st = eng.interior_state()
-    np.savez(os.path.join(outdir, "r%d.npz" % rank), **dict(zip("puvtq", st)))
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), **dict(zip("puvtqg", st)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -92,6 +93,13 @@ def _ic_pe(geom):
     t = temperature.to_potential_temp(300 + rng.standard_normal((L, H, W)), p * geom.sig + geom.ptop)
     q = 3e-6 * (1 + 0.1 * rng.random((L, H, W)))
     return p, u, v, t, q
+
+
+UTC0 = 5 * 3600.0
+
+
+def _ic_gt(geom):
+    return 288.0 + np.random.default_rng(10).standard_normal((geom.height, geom.width))
 
 
 def test_split_rows():
@@ -155,6 +163,33 @@ def test_banded_pe25d_equals_single_domain(tmp_path, world, edge_first):
     for k, want in zip("puvtq", st):
         got = np.concatenate([pp[k] for pp in parts], axis=0 if k == "p" else 1)
         assert np.array_equal(got, want), k
+
+
+@pytest.mark.parametrize("edge_first", [False, True])
+@pytest.mark.parametrize("world", [2, 3])
+def test_banded_pe25d_with_physics_equals_single_domain(tmp_path, world, edge_first):
+    """BASELINE configs[4] on latitude bands: dynamics + solar_timestep every step.  The radiation changes theta and
+    the ground temperature AFTER the post-corrector exchange; the bands radiate their ghost rows locally (the ghost
+    rows of gt travel with the messages), so the next predictor's edge rows read current values without a third
+    exchange per step.  Bit for bit the single domain (the oracle: matsuno_timestep, then solar_timestep)."""
+    from oracle import dynamics, physics, geometry as ogeo
+    hwl, steps = (12, 16, 3), 3
+    mp.spawn(_worker_pe, args=(world, _free_port(), hwl, steps, str(tmp_path), edge_first, True), nprocs=world,
+             join=True)
+    H, W, L = hwl
+    geom = ogeo.gen_geometry(H, W, L, sig_func=ogeo.manabe_sig)
+    geom.heightmap[H // 2, 3] = 300.0
+    st, gt, utc = _ic_pe(geom), _ic_gt(geom), UTC0
+    for _ in range(steps):
+        st = list(dynamics.matsuno_timestep(*st, 120.0, geom))
+        st[3], gt = physics.solar_timestep(st[3], st[0], gt, 120.0, utc, geom)
+        utc += 120.0
+    parts = [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(world)]
+    for k, want in zip("puvtqg", list(st) + [gt]):
+        got = np.concatenate([pp[k] for pp in parts], axis=0 if k in "pg" else 1)
+        assert np.array_equal(got, want), k
+    # the physics did something, and a band that skipped its ghost rows would differ: theta moved
+    assert not np.array_equal(st[3], dynamics.matsuno_timestep(*_ic_pe(geom), 120.0, geom)[3])
 
 
 def test_rccl_unique_id_survives_transport():

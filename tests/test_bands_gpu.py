@@ -37,6 +37,13 @@ def _ic_pe(geom):
     return p, u, v, t, q
 
 
+UTC0 = 5 * 3600.0
+
+
+def _ic_gt(H, W):
+    return 288.0 + np.random.default_rng(13).standard_normal((H, W))
+
+
 def _exchange(cores, torch):
     """ring exchange by device copies: the rows a band packs on side s land in the neighbour's
     opposite ghost"""
@@ -423,12 +430,15 @@ def _rccl_self_worker(rank, port, model, outdir):
         ring.self_check()
     else:
         ring = dist
-    if model == "pe":
+    phys = model == "pephys"
+    if model in ("pe", "pephys"):
         H, W, L, steps, dt = 23, 36, 9, 5, 120.0
         geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
         c = g.Core(g._lib.PE25D, W, H, L, geom=geom, nranks=2, rank=0, global_height=H, row0=0,
                    stream=torch.cuda.current_stream().cuda_stream)
         c.set_state(*_ic_pe(geom))
+        if phys:
+            c.set_ground(_ic_gt(H, W))
     else:
         H, W, steps, dt = 64, 130, 11, 300.0
         c = g.Core(g._lib.SW2D_TEMP, W, H, dx=300e3, tracer=g._lib.TRACER_VANLEER, nranks=2, rank=0,
@@ -436,13 +446,15 @@ def _rccl_self_worker(rank, port, model, outdir):
                    halo_steps=1 if model == "c3" else 4)
         c.set_state(**_ic2d((H, W)))
     eng = HipBandEngine(c, torch)                 # stream-aware: the exchange is ordered on streams only
+    if phys:
+        eng.set_physics(geom, UTC0)
     runner = BandRunner(eng, 0, 2, ring, north=0, south=0)
     assert runner.native == (direct and "GCM_BAND_HOST_LOOP" not in os.environ)
     runner.run(steps - 2, dt)
     runner.run(2, dt)                             # a second call continues on the exchanged ghosts
     torch.cuda.synchronize()
-    st = c.get_state()
-    np.savez(os.path.join(outdir, "self.npz"), **{k: a for k, a in zip("puvtq", st) if a is not None})
+    st = c.get_state() + ([c.get_ground()] if phys else [])
+    np.savez(os.path.join(outdir, "self.npz"), **{k: a for k, a in zip("puvtqg", st) if a is not None})
     c.close()
     if direct:
         ring.close()
@@ -450,7 +462,7 @@ def _rccl_self_worker(rank, port, model, outdir):
 
 
 @pytest.mark.parametrize("model", ["pe-direct", "c3-direct", "c3deep-direct", "pe-direct-hostloop",
-                                   "c3deep-direct-hostloop", "pe", "c3deep"])
+                                   "c3deep-direct-hostloop", "pe", "c3deep", "pephys-direct", "pephys-direct-hostloop"])
 def test_band_runner_over_rccl_self_ring(tmp_path, model):
     """The production exchange paths on the one GPU of the test box -- RCCL called directly
     (gcmiipy_amd.rccl: ncclSend/ncclRecv groups on the library's comm stream, posted by the LIBRARY
@@ -466,24 +478,27 @@ def test_band_runner_over_rccl_self_ring(tmp_path, model):
     mp.spawn(_rccl_self_worker, args=(_free_port(), model, str(tmp_path)), nprocs=1, join=True)
     got = np.load(os.path.join(str(tmp_path), "self.npz"))
     model = model.split("-")[0]
-    if model == "pe":
+    if model in ("pe", "pephys"):
         H, W, L = 23, 36, 9
         geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
         ref = g.Core(g._lib.PE25D, W, H, L, geom=geom)
         ref.set_state(*_ic_pe(geom))
+        if model == "pephys":                      # the single domain: gcm_step with the physics registered
+            ref.set_ground(_ic_gt(H, W))
+            ref.set_physics(geom, UTC0)
         ref.step(5, 120.0)
     else:
         H, W = 64, 130
         ref = g.Core(g._lib.SW2D_TEMP, W, H, dx=300e3, tracer=g._lib.TRACER_VANLEER)
         ref.set_state(**_ic2d((H, W)))
         ref.step(11, 300.0)
-    want = ref.get_state()
+    want = ref.get_state() + ([ref.get_ground()] if model == "pephys" else [])
     ref.close()
-    for k, w in zip("puvtq", want):
+    for k, w in zip("puvtqg", want):
         assert np.array_equal(got[k], w), k
 
 
-@pytest.mark.parametrize("model", ["pe", "c3", "c3deep", "c3deep-overlap", "c3deep8-overlap"])
+@pytest.mark.parametrize("model", ["pe", "c3", "c3deep", "c3deep-overlap", "c3deep8-overlap", "pephys"])
 def test_band_run_native_loopback_equals_single_domain(model):
     """gcm_band_run with the loopback exchange (gcm_set_exchange without RCCL entry points): the band
     is its own neighbour, i.e. the periodic single domain -- bit-identical to it, and to the
@@ -498,7 +513,8 @@ def test_band_run_native_loopback_equals_single_domain(model):
     from gcmiipy_amd import geometry
     from gcmiipy_amd.bands import BandRunner, HipBandEngine, LoopbackExchange
     from gcmiipy_amd.core import GcmError
-    if model == "pe":
+    phys = model == "pephys"
+    if model in ("pe", "pephys"):
         H, W, L, steps, dt = 23, 36, 9, 5, 120.0
         geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
         mk = lambda **kw: g.Core(g._lib.PE25D, W, H, L, geom=geom, **kw)
@@ -509,8 +525,15 @@ def test_band_run_native_loopback_equals_single_domain(model):
         ic = _ic2d((H, W))
     ref = mk()
     ref.set_state(**ic)
-    ref.step(steps, dt)
-    want = ref.get_state()
+    if phys:
+        # explicit calls on the single domain: step, solar_step at the clock, clock += dt (no_limits_2_5d.py:229-234)
+        ref.set_ground(_ic_gt(H, W))
+        for n in range(steps):
+            ref.step(1, dt)
+            ref.solar_step(geom, dt, UTC0 + n * dt)
+    else:
+        ref.step(steps, dt)
+    want = ref.get_state() + ([ref.get_ground()] if phys else [])
     with pytest.raises(GcmError, match="not a latitude band"):
         ref.band_run(1, dt)
     ref.close()
@@ -520,6 +543,9 @@ def test_band_run_native_loopback_equals_single_domain(model):
     with pytest.raises(GcmError, match="no exchange registered"):
         c.band_run(1, dt)
     eng = HipBandEngine(c, torch)
+    if phys:
+        c.set_ground(_ic_gt(H, W))
+        eng.set_physics(geom, UTC0)
     runner = BandRunner(eng, 0, 2, LoopbackExchange(), north=0, south=0)
     assert runner.native
     if overlap:
@@ -530,7 +556,135 @@ def test_band_run_native_loopback_equals_single_domain(model):
         runner.run(3, dt)
         runner.run(steps - 3, dt)
     torch.cuda.synchronize()
-    got = c.get_state()
+    got = c.get_state() + ([c.get_ground()] if phys else [])
+    if phys:
+        assert c.utc() == UTC0 + steps * dt
     c.close()
-    for k, a, b in zip("puvtq", got, want):
+    for k, a, b in zip("puvtqg", got, want):
         assert (a is None and b is None) or np.array_equal(a, b), k
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_eight_bands_with_physics_equal_single_domain(dtype):
+    """BASELINE configs[4] on its stated decomposition: 8 latitude bands of a (40, 64, 2880) grid, dynamics +
+    solar_timestep for 3 steps, the bands stepped in ONE process with the ghost rows moved by device copies.  The
+    radiation changes theta and the ground temperature after the post-corrector exchange; every band radiates its
+    ghost rows locally (the ghost rows of gt travel in the messages), so the next predictor reads current values.
+    Bit for bit the single domain, ground temperature included."""
+    import torch
+    import gcmiipy_amd as g
+    from gcmiipy_amd import geometry
+    from gcmiipy_amd.bands import split_rows
+    H, W, L, steps, nb, dt = 64, 2880, 40, 3, 8, 60.0
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    ic, gt = _ic_pe(geom), _ic_gt(H, W)
+    ref = g.Core(g._lib.PE25D, W, H, L, geom=geom, dtype=dtype)
+    ref.set_state(*ic)
+    ref.set_ground(gt)
+    dyn_only = None
+    for n in range(steps):
+        ref.step(1, dt)
+        if n == 0:
+            dyn_only = ref.get_state((3,))[3]
+        ref.solar_step(geom, dt, UTC0 + n * dt)
+    want, want_gt = ref.get_state(), ref.get_ground()
+    ref.close()
+    cores = []
+    for r, (row0, n) in enumerate(split_rows(H, nb)):
+        c = g.Core(g._lib.PE25D, W, n, L, geom=geom, nranks=nb, rank=r, global_height=H, row0=row0, dtype=dtype)
+        sl = slice(row0, row0 + n)
+        c.set_state(ic[0][sl], *[a[:, sl] for a in ic[1:]])
+        c.set_ground(gt[sl])
+        cores.append(c)
+    bufs = [[torch.empty(c.halo_bytes(), dtype=torch.uint8, device="cuda") for _ in (0, 1)] for c in cores]
+
+    def exchange():
+        for r, c in enumerate(cores):
+            c.halo_pack(0, bufs[r][0].data_ptr())
+            c.halo_pack(1, bufs[r][1].data_ptr())
+        torch.cuda.synchronize()
+        for r, c in enumerate(cores):
+            c.halo_unpack(1, bufs[(r + 1) % nb][0].data_ptr())
+            c.halo_unpack(0, bufs[(r - 1) % nb][1].data_ptr())
+        torch.cuda.synchronize()
+    exchange()                               # once: the ghost rows of the initial state and of gt
+    for n in range(steps):                   # the order of gcm_band_run: two exchanges per step, none after the physics
+        for c in cores:
+            c.step_interior(dt)              # predictor
+        exchange()                           # predicted state
+        for c in cores:
+            c.step_boundary(dt)              # corrector
+        exchange()                           # new state, BEFORE the radiation changes theta
+        for c in cores:
+            c.solar_step(geom, dt, UTC0 + n * dt)      # own rows and ghost rows
+    parts = [c.get_state() for c in cores]
+    got_gt = np.concatenate([c.get_ground() for c in cores], axis=0)
+    for c in cores:
+        c.close()
+    for f in range(5):
+        got = np.concatenate([x[f] for x in parts], axis=0 if f == 0 else 1)
+        assert np.array_equal(got, want[f]), "puvtq"[f]
+    assert np.array_equal(got_gt, want_gt)
+    assert not np.array_equal(dyn_only, want[3])
+
+
+@pytest.mark.parametrize("phys", [False, True])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_band_run_chains_at_overlapping_size(dtype, phys, monkeypatch):
+    """gcm_band_run keeps two chains of launches on two streams with no join per stage; at the small sizes of the
+    other band tests a kernel is over before the other chain starts, so a missing dependency could not show.  Here
+    the band is 48 rows x 1440 columns x 24 levels (edge rows marched in level segments, kernels of tens of
+    microseconds on either stream), five steps inside gcm_band_run calls, fp64 and fp32, with the loopback exchange
+    (the band is its own neighbour = the periodic single domain).  Three orchestrations -- the two chains, one
+    stream only (GCM_PE_SINGLE_STREAM=1), the exchange on the comm stream with a join per stage
+    (GCM_BAND_COMM_STREAM=1) -- must all give the single domain's bits; a solar_timestep and a gcm_set_state between
+    runs exercise the reset of the queued ghost-row work (ghost_ready)."""
+    import torch
+    import gcmiipy_amd as g
+    from gcmiipy_amd import geometry
+    from gcmiipy_amd.bands import BandRunner, HipBandEngine, LoopbackExchange
+    H, W, L, dt = 48, 1440, 24, 1.0
+    geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
+    ic, gt = _ic_pe(geom), _ic_gt(H, W)
+
+    def drive(core, run):
+        """2 steps, an explicit solar_timestep, 3 steps; then the initial state again and 2 steps"""
+        core.set_state(*ic)
+        core.set_ground(gt)
+        run(2)
+        core.solar_step(geom, dt, 7 * 3600.0)
+        run(3)
+        a = core.get_state() + [core.get_ground()]
+        core.set_state(*ic)
+        core.set_ground(gt)
+        if phys:
+            core.set_physics(geom, UTC0)          # the clock starts again with the state
+        run(2)
+        return a, core.get_state() + [core.get_ground()]
+
+    ref = g.Core(g._lib.PE25D, W, H, L, geom=geom, dtype=dtype)
+    if phys:
+        ref.set_physics(geom, UTC0)
+    want = drive(ref, lambda n: ref.step(n, dt))
+    ref.close()
+    for env in ({}, {"GCM_PE_SINGLE_STREAM": "1"}, {"GCM_BAND_COMM_STREAM": "1"}):
+        for k in ("GCM_PE_SINGLE_STREAM", "GCM_BAND_COMM_STREAM"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = g.Core(g._lib.PE25D, W, H, L, geom=geom, nranks=2, rank=0, global_height=H, row0=0, dtype=dtype,
+                   stream=torch.cuda.current_stream().cuda_stream)
+        eng = HipBandEngine(c, torch)
+        if phys:
+            eng.set_physics(geom, UTC0)
+        runner = BandRunner(eng, 0, 2, LoopbackExchange(), north=0, south=0)
+        assert runner.native
+
+        def run(n):
+            runner.run(n, dt)
+            torch.cuda.synchronize()
+        got = drive(c, run)
+        c.close()
+        for part, (ga, wa) in enumerate(zip(got, want)):
+            for k, a, b in zip("puvtqg", ga, wa):
+                assert np.array_equal(a, b), (env, part, k, rel_err(a, b))
