@@ -63,7 +63,7 @@ WORKLOADS = {
                     "(BASELINE configs[4])", 1440, 2880, 40, "PE25D", None, 40.0 + 16.0 / 40, 1.0),
 }
 PHYS_UTC0 = 6 * 3600.0
-ALSO = ("c2", "c3", "c4", "c4_f32", "c5_phys")     # secondary workloads of the default run (c5_phys: N = 1 only)
+ALSO = ("c2", "c3", "c4", "c4_f32", "c5_phys")     # secondary workloads of the default run (N > 1: c3, c4, c5_phys)
 DX = 300e3
 
 
@@ -193,26 +193,16 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
 
         phys = "phys" in name
         if phys:
+            # configs[4]: every step = the dynamics step + solar_timestep at the handle's clock (gcm_set_physics), on one
+            # GPU inside gcm_step, on a latitude band inside gcm_band_run (ghost rows radiated locally: no third exchange)
             core.set_ground(np.full((nrows, W), 288.0))
-        clock = [0]
+            if eng is not None:
+                eng.set_physics(geom, PHYS_UTC0)
+            else:
+                core.set_physics(geom, PHYS_UTC0)
 
         def run_chunk(n, timed):
-            if phys:
-                # configs[4]: dynamics step + solar_timestep, both asynchronous on the handle's stream
-                if world > 1:
-                    raise SystemExit("bench.py: c5_phys is a 1-GPU workload here")
-                ev = None
-                if timed:
-                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                    ev[0].record()
-                for _ in range(n):
-                    core.step(1, dt)
-                    core.solar_step(geom, dt, PHYS_UTC0 + clock[0] * dt)
-                    clock[0] += 1
-                if timed:
-                    ev[1].record()
-                    region.setdefault("events", []).append(ev)
-            elif world == 1:
+            if world == 1:
                 if timed:   # same launches, bracketed by HIP events on the launch stream
                     region["ms"] = region.get("ms", 0.0) + core.time_steps(n, dt, per_kernel=False)[0]
                 else:
@@ -299,12 +289,14 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
     # The timed region: a block of exactly `steps` steps between two fences (barrier + synchronize),
     # repeated until MIN_TIMED_S seconds have been timed (every rank sees the same all-reduced block
     # times, so all stop together); the median block is the result.
-    blocks, t_queued = [], 0.0
+    blocks, own_blocks, t_queued = [], [], 0.0
     while True:
         fence()
         t0 = time.perf_counter()
         run(steps, timed=True)
         t_queued += time.perf_counter() - t0          # the host has queued all K steps
+        torch.cuda.synchronize()
+        own_blocks.append(time.perf_counter() - t0)   # this rank's own band, before it waits for the others
         fence()
         el = time.perf_counter() - t0
         if dist is not None and not solo:
@@ -316,6 +308,15 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
             break
     el = float(np.median(blocks))
     t_queued /= len(blocks)
+    # N > 1: every rank's own median (its band done, before the closing barrier), gathered so that the line shows the
+    # slowest and the fastest band
+    per_rank_ms = None
+    if dist is not None and not solo and world > 1:
+        tt = torch.tensor([float(np.median(own_blocks)) / steps * 1e3], dtype=torch.float64,
+                          device="cuda" if cx.backend == "nccl" else "cpu")
+        allv = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allv, tt)
+        per_rank_ms = [float(x.item()) for x in allv]
     if active:
         assert core.diag(_lib.DIAG_ANY_NAN) == 0.0, "state went NaN during the timed run"
         cells = H * W * L
@@ -332,6 +333,20 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
                "decomposition": "%d latitude band(s)%s" % (
                    world, ", ghost rows exchanged every %d steps" % k if world > 1 and k > 1 else "")}
         if world > 1:
+            # what makes the N > 1 line readable on its own: whole-job roofline, every band's own time, the bytes the
+            # ghost-row exchange moves, and how many ranks the RCCL communicator really has
+            per_step = 2.0 if model == "PE25D" else 1.0 / k                      # exchanges per step
+            hb = core.halo_bytes()
+            res["roofline"] = {"bound": "hbm", "achieved": value * bpc / 1e9, "peak": world * HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": value * bpc / (world * HBM_PEAK_GBS * 1e9), "traffic": None,
+                               "kernel": "whole job: %d latitude bands, algorithmic bytes of the global grid over the "
+                                         "slowest rank's wall time, against %d x %.0f GB/s" % (world, world, HBM_PEAK_GBS)}
+            res["band_ms_per_step"] = {"max": max(per_rank_ms), "min": min(per_rank_ms), "per_rank": per_rank_ms}
+            res["exchange_bytes"] = {"message_bytes": hb, "messages_per_exchange_per_rank": 2,
+                                     "exchanges_per_step": per_step,
+                                     "sent_per_rank_per_step": 2 * hb * per_step,
+                                     "whole_job_per_step": world * 2 * hb * per_step}
+            res["rccl_ranks"] = cx.ring.count() if hasattr(cx.ring, "count") else None
             # diagnostics for the multi-GPU line: how long the host needs to queue a step, and what
             # the same band costs with the exchange replaced by a device-local copy (same launches
             # and stream dependencies, no xGMI traffic) -- the difference to ms_per_step is what the
@@ -370,8 +385,6 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
             # back-to-back launches leave no gap (rocprofv3 trace: next start == previous end).
             # "kernel_ms_isolated" is a second pass with an event pair around every launch
             # (idle gaps between launches let the chip clock higher, so it reads lower).
-            if "events" in region:                     # c5_phys: torch events around every block
-                region["ms"] = sum(e0.elapsed_time(e1) for e0, e1 in region["events"])
             launches_timed = steps * len(blocks)
             kiso = None
             launches = 1
@@ -447,8 +460,10 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
     return res
 
 
-def bring_up_direct_rccl(cx, torch, dist):
-    """The ghost rows go over RCCL called directly (gcmiipy_amd.rccl; the library posts the exchange
+def bring_up_direct_rccl(cx, torch, dist, rccl_cls=None, device="cuda", timeout_s=None):
+    """(rccl_cls / device / timeout_s: what the CPU tests replace -- a stand-in for gcmiipy_amd.rccl.RcclP2P over a gloo
+    group, tests/test_bench_cpu.py -- the control flow is the product's.)
+    The ghost rows go over RCCL called directly (gcmiipy_amd.rccl; the library posts the exchange
     itself, gcm_band_run).  Bringing that communicator up between devices cannot be rehearsed on the
     one-GPU development box, so every step is agreed on by ALL ranks through torch.distributed
     collectives (a gloo group on the CPU, created before the bring-up) issued from the main thread in
@@ -472,7 +487,10 @@ def bring_up_direct_rccl(cx, torch, dist):
 
     err, uid = None, None
     try:
-        from gcmiipy_amd.rccl import RcclP2P
+        if rccl_cls is None:
+            from gcmiipy_amd.rccl import RcclP2P
+        else:
+            RcclP2P = rccl_cls
         if cx.rank == 0:
             uid = RcclP2P.new_unique_id()
     except Exception as e:          # noqa: BLE001
@@ -481,7 +499,7 @@ def bring_up_direct_rccl(cx, torch, dist):
         cx.exchange_fallback = err or "librccl / unique id failed on another rank"
         print("bench.py: direct RCCL exchange unavailable (%s); using torch.distributed" % cx.exchange_fallback, file=sys.stderr)
         return
-    box_t = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    box_t = torch.zeros(128, dtype=torch.uint8, device=device)
     if cx.rank == 0:
         box_t.copy_(torch.frombuffer(bytearray(uid), dtype=torch.uint8))
     dist.broadcast(box_t, src=0)
@@ -490,7 +508,8 @@ def bring_up_direct_rccl(cx, torch, dist):
 
     def init():
         try:
-            torch.cuda.set_device(cx.local)           # the HIP device is per thread
+            if device == "cuda":
+                torch.cuda.set_device(cx.local)       # the HIP device is per thread
             ring = RcclP2P(None, cx.rank, cx.world, uid_bytes=uid)
             ring.self_check()
             box["ring"] = ring
@@ -499,7 +518,7 @@ def bring_up_direct_rccl(cx, torch, dist):
 
     th = threading.Thread(target=init, daemon=True)
     th.start()
-    th.join(float(os.environ.get("GCM_BENCH_RCCL_TIMEOUT_S", "120")))
+    th.join(float(os.environ.get("GCM_BENCH_RCCL_TIMEOUT_S", "120")) if timeout_s is None else timeout_s)
     cx.stuck = th.is_alive()
     if agree("ring" in box):
         cx.ring, cx.exchange = box["ring"], "RCCL ncclSend/ncclRecv groups posted by the library (gcm_band_run)"
@@ -509,21 +528,41 @@ def bring_up_direct_rccl(cx, torch, dist):
     print("bench.py: direct RCCL exchange unavailable (%s); using torch.distributed" % cx.exchange_fallback, file=sys.stderr)
 
 
+def agree_stuck(cx, torch, dist):
+    """one verdict for the whole job: if a bring-up thread is stuck on ANY rank, every rank reports the fallback, keeps
+    off the device collectives' path of that thread and exits non-zero (finish)"""
+    t = torch.tensor([1 if cx.stuck else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=cx.cpu_group)
+    cx.stuck = int(t.item()) == 1
+    return cx.stuck
+
+
+def finish(cx, out):
+    """rank 0 prints the ONE JSON line; a job with a bring-up thread still inside RCCL has said so in that line
+    (exchange_fallback) and now says so with its exit code too -- non-zero, from THIS process, without waiting for
+    that thread and without starting or exec'ing anything"""
+    if cx.rank == 0:
+        print(json.dumps(out), flush=True)
+    if cx.stuck:
+        sys.stdout.flush()
+        os._exit(4)
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD job
     (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1) from a parent that has not
     imported torch nor touched the GPU, pass the arguments through, let rank 0's JSON line go to the
     inherited stdout and return the job's exit code.  Nothing is re-exec'ed."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    import uuid
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
+    # the launcher picks AND HOLDS its rendezvous port itself (c10d store on 127.0.0.1:0): nothing is probed here
+    # and bound again later, so two benches on one node cannot collide on a port
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--rdzv-backend=c10d", "--rdzv-endpoint=127.0.0.1:0", "--rdzv-id=" + uuid.uuid4().hex,
+           "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
 
@@ -552,6 +591,13 @@ def main():
                          % (a.gpus, cx.world))
     if os.environ.get("GCM_BENCH_BACKEND", "nccl") != "nccl":
         cx.local = 0
+    # --gpus N against the devices this node shows, BEFORE any collective: a rank that cannot have a device of its own
+    # says so and the job ends non-zero (device_count() does not initialise the GPU)
+    if cx.local >= torch.cuda.device_count():
+        if cx.rank == 0:
+            print("bench.py: --gpus %d but this node shows %d GPU(s) (GCM_BENCH_BACKEND=gloo rehearses the ranks on one)"
+                  % (a.gpus, torch.cuda.device_count()), file=sys.stderr)
+        raise SystemExit(3)
     torch.cuda.set_device(cx.local)
     cx.dist = None
     cx.ring, cx.exchange, cx.stuck, cx.exchange_fallback = None, None, False, None
@@ -575,11 +621,7 @@ def main():
         cx.cpu_group = dist.new_group(backend="gloo") if cx.backend == "nccl" else None
         if cx.backend == "nccl" and os.environ.get("GCM_BENCH_EXCHANGE", "rccl") == "rccl":
             bring_up_direct_rccl(cx, torch, dist)
-            # one verdict for the whole job: if a bring-up thread is stuck on ANY rank, every rank reports
-            # the fallback, keeps off the device collectives' path of that thread and exits non-zero
-            t = torch.tensor([1 if cx.stuck else 0], dtype=torch.int32)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=cx.cpu_group)
-            cx.stuck = int(t.item()) == 1
+            agree_stuck(cx, torch, dist)
 
     main_res = run_workload(cx, a.workload, a.steps, a.warmup, a.variant)
     also, cpu_cache = {}, {}
@@ -589,12 +631,14 @@ def main():
                 continue
             if cx.world > 1 and name == "c2":
                 continue                                   # 360 rows: not a multi-GPU workload
-            if cx.world > 1 and name in ("c4_f32", "c5_phys"):
+            if cx.world > 1 and name == "c4_f32":
                 continue
             # c2: the noise IC goes unstable (in the reference too) near step 1300
             st, wu = {"c2": (600, 50), "c3": (100, 10), "c4": (16, 3), "c4_f32": (16, 3), "c5_phys": (6, 2)}[name]
             if cx.world > 1 and name == "c4":
                 st, wu = 60, 10                            # a band's step is a fraction of a millisecond
+            if cx.world > 1 and name == "c5_phys":
+                st, wu = 12, 3
             r = run_workload(cx, name, st, wu, want_kernel=cx.world == 1)
             if cx.world > 1:                               # same-run single-GPU reference (rank 0 alone)
                 r1 = run_workload(cx, name, max(st // 2, 4), 2, world=1, want_kernel=False)
@@ -629,6 +673,8 @@ def main():
         if cx.world > 1:
             out["exchange"] = cx.exchange
             out["exchange_fallback"] = cx.exchange_fallback     # null: the direct RCCL ring came up on every rank
+            for kk in ("rccl_ranks", "band_ms_per_step", "exchange_bytes"):
+                out[kk] = main_res.get(kk)
         if "diagnostics" in main_res:
             out["diagnostics"] = main_res["diagnostics"]
         if "device_copy_same_bytes" in main_res:
@@ -639,13 +685,7 @@ def main():
             out["also"] = also
     if cx.dist is not None:
         cx.dist.barrier()
-    if cx.rank == 0:
-        print(json.dumps(out), flush=True)
-    if cx.stuck:
-        # a bring-up thread still sits inside RCCL: the line above says so (exchange_fallback); this is a
-        # degraded run and the process says so too -- non-zero, and without waiting for that thread
-        sys.stdout.flush()
-        os._exit(4)
+    finish(cx, out if cx.rank == 0 else None)
     if cx.dist is not None:
         cx.dist.destroy_process_group()
 

@@ -755,6 +755,10 @@ static int band_post(gcm_handle *h, bool on_compute_stream = false, hipStream_t 
         }
     } else {
         // loopback: what goes north arrives as this band's own south ghost rows and vice versa
+        // (GCM_BAND_EXCHANGE_DELAY_US: a stand-in for the transfer time between two devices, which one GPU cannot
+        // show -- tools/tools_band_time.py sweeps it to see how much exchange latency an orchestration hides)
+        static const double delay_us = getenv("GCM_BAND_EXCHANGE_DELAY_US") ? atof(getenv("GCM_BAND_EXCHANGE_DELAY_US")) : 0.0;
+        launch_spin(cs, delay_us);
         HIPCHK(h, hipMemcpyAsync(x.recv_south, x.send_north, nbytes, hipMemcpyDeviceToDevice, cs));
         HIPCHK(h, hipMemcpyAsync(x.recv_north, x.send_south, nbytes, hipMemcpyDeviceToDevice, cs));
     }
@@ -798,7 +802,7 @@ static int band_step_pe(gcm_handle *h, double dt) {
     hipStream_t ax = h->on_comm ? nullptr : pe25d_aux_stream(h->pe);
     const int H = h->H;
     for (int stage = 0; stage < 2; ++stage) {
-        if ((rc = pe25d_step_phase(h->pe, 2 * stage, dt, h->stream, &h->err))) return rc;
+        if ((rc = pe25d_step_phase(h->pe, 2 * stage, dt, h->stream, &h->err, ax != nullptr))) return rc;
         if (ax) {
             if ((rc = band_post(h, false, ax))) return rc;
             if ((rc = gcm_halo_unpack2(h, h->xch.recv_north, h->xch.recv_south, ax))) return rc;
@@ -809,7 +813,7 @@ static int band_step_pe(gcm_handle *h, double dt) {
             if ((rc = pe25d_prep_ghost_rows(h->pe, &h->err))) return rc;
             h->join_pending = true;
         }
-        if ((rc = pe25d_step_phase(h->pe, 2 * stage + 1, dt, h->stream, &h->err))) return rc;
+        if ((rc = pe25d_step_phase(h->pe, 2 * stage + 1, dt, h->stream, &h->err, ax != nullptr))) return rc;
         if (!ax) {
             if ((rc = pe25d_wait_edges(h->pe, h->comm, &h->err))) return rc;
             if ((rc = band_exchange(h))) return rc;
@@ -856,6 +860,7 @@ int gcm_band_run(gcm_handle *h, int nsteps, double dt) {
             HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_comm, 0));
             h->join_pending = false;
         }
+        pe25d_join_third_stream(h->pe, h->stream);
         return GCM_OK;
     }
     const int k = h->G / kGhost;                            // steps per exchange

@@ -58,6 +58,7 @@ struct PeArgsT {
     int jb0, jb1;                          // second row range of the same launch (K4 edge rows), or empty
     int nseg;                              // K4 marches the column in nseg level segments (1: whole column)
     int cs_rows, geo_j0, geo_j1;           // pe_geopot_kernel: also form the rows' column sums; rows to form phi for
+    int spu_j0, spu_j1, pit_j0, pit_j1;    // K1 (looping form): of the launch's rows, those it forms spu / pit for
     long part_stride;                      // elements per slab of `part`
     T dt, inv_dy, ptop;
 };

@@ -58,15 +58,20 @@ void pe_spu_filter_loop_kernel(PeArgsT<T> a, int pairs_per_wg, int pit_block) {
     using V = typename Vec2<T>::type;
     extern __shared__ unsigned char lds_raw[];
     V *x = (V *)lds_raw;
+    // rows of the launch: [j0, j1), then [jb0, jb1) (a band's launch for the rows that need ghost data: rows 0, 1 and
+    // H - 1, H); of those, spu is formed for [spu_j0, spu_j1) and pit for [pit_j0, pit_j1) (uniform early exits)
+    const int nr0 = a.j1 - a.j0;
+    const int j = (int)blockIdx.x < nr0 ? a.j0 + (int)blockIdx.x : a.jb0 + ((int)blockIdx.x - nr0);
     if ((int)blockIdx.y == pit_block) {
         // one more workgroup per row: pit and p_n from the 2-D column sums (pe_pit2d_row) -- independent
         // of the pairs' transforms, and a launch less on the stage's dependency chain
-        pe_pit2d_row<T, MAXR, MASK>(a, x, blockIdx.x);
+        if (j < a.pit_j0 || j >= a.pit_j1) return;
+        pe_pit2d_row<T, MAXR, MASK>(a, x, j);
         return;
     }
+    if (j < a.spu_j0 || j >= a.spu_j1) return;
     const Idx ix{a.W, a.H, a.L, a.wrap};
     const int W = a.W, L = a.L;
-    const int j = a.j0 + blockIdx.x;
     const int npairs = (L + 1) / 2;
     const int pb0 = blockIdx.y * pairs_per_wg, pb1 = min(pb0 + pairs_per_wg, npairs);
     if (pb0 >= pb1) return;                                      // uniform

@@ -10,7 +10,7 @@ namespace gcm {
 template <typename T, int MAXR, unsigned MASK = 0>
 __global__ __launch_bounds__(512) void pe_pit2d_kernel(PeArgsT<T> a) {
     extern __shared__ unsigned char lds_raw[];
-    pe_pit2d_row<T, MAXR, MASK>(a, (typename Vec2<T>::type *)lds_raw, blockIdx.x);
+    pe_pit2d_row<T, MAXR, MASK>(a, (typename Vec2<T>::type *)lds_raw, a.j0 + (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------- K3: pgfu = filter(pgu + phiu)

@@ -21,13 +21,16 @@ int pe25d_get(Pe25d *m, bool star, double *p, double *u, double *v, double *t, d
               hipStream_t s, std::string *err);
 int pe25d_step(Pe25d *m, double dt, hipStream_t s, std::string *err);
 int pe25d_step_part(Pe25d *m, int part, double dt, hipStream_t s, std::string *err);
-int pe25d_step_phase(Pe25d *m, int phase, double dt, hipStream_t s, std::string *err);
+// chained: the call belongs to gcm_band_run's own sequence (the library knows everything queued between two stages)
+int pe25d_step_phase(Pe25d *m, int phase, double dt, hipStream_t s, std::string *err, bool chained = false);
 int pe25d_set_halo_buffers(Pe25d *m, void *north, void *south, hipStream_t s, std::string *err);
 int pe25d_wait_edges(Pe25d *m, hipStream_t s, std::string *err);
 int pe25d_prep_ghost_rows(Pe25d *m, std::string *err);   // gcm_band_run: behind the unpack on the second stream
 hipStream_t pe25d_aux_stream(const Pe25d *m);
+void pe25d_join_third_stream(Pe25d *m, hipStream_t s);
 // a new non-blocking stream that demonstrably runs beside `main` (and `other`, may be null)
 hipStream_t concurrent_stream(hipStream_t main, hipStream_t other);
+void launch_spin(hipStream_t s, double us);   // GCM_BAND_EXCHANGE_DELAY_US: the loopback exchange takes that long
 int pe25d_half(Pe25d *m, int stage, double dt, hipStream_t s, std::string *err);
 size_t pe25d_halo_bytes(const Pe25d *m);
 int pe25d_halo_segments(Pe25d *m, bool pack, int side, void *dev_buf, SegCopy *c, std::string *err);

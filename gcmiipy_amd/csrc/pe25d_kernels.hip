@@ -17,6 +17,8 @@
 // it acts on both parts independently), multiplied by S[j][n] and transformed back.
 #include "pe25d_kernels.h"
 
+#include <hip/hip_ext.h>
+
 #include "pe25d_dev.h"
 
 namespace gcm {
@@ -507,12 +509,24 @@ struct Pe25d {
     std::vector<hipEvent_t> *ev = nullptr;
     size_t *ev_used = nullptr;
     hipStream_t aux = nullptr;                  // second stream of a stage (K2a -> K3), see half_t
+    hipStream_t aux2 = nullptr;                 // bands: third stream, K1 of the band's OWN rows (no ghost data: off the exchange chain)
+    hipEvent_t ev_cs = nullptr;                 // aux2: the own edge rows' column sums of the state just produced are in place
+    int edge_cs_set = -1;                       // state set whose own edge rows' column sums were queued on aux2 (nseg_edge > 1)
+    bool k1_split = true;                       // GCM_PE_K1_SPLIT=0: K1 of all rows behind the exchange, as in round 3
+    // The events a stage's chains hand each other are signalled by the producing kernel's OWN completion
+    // (hipExtLaunchKernelGGL's stopEvent) where a kernel is what they follow: a hipEventRecord is a packet of
+    // its own behind the kernel and costs the stream 3 us (tools/micro/sync_cost.hip: 8.9 vs 5.9 us per
+    // kernel + record; with a stop event 5.95), four of them per stage on the band's long chain.
+    bool stop_events = true;                    // GCM_PE_STOP_EVENTS=0: records, as in round 3
+    hipEvent_t ev_k4 = nullptr;                 // completion of the last K4 launch on the caller's stream
+    bool k4_fork_valid = false;                 // nothing the second stream must follow was queued on the caller's stream since
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // latitude band with registered send buffers: the edge rows of a stage are updated and packed
     // on `aux` while the interior rows run on the caller's stream (pe25d_step_phase)
     void *send_buf[2] = {nullptr, nullptr};
     hipEvent_t ev_a = nullptr, ev_edges = nullptr;
     bool edges_pending = false;
+    bool edges_ev_valid = false;                // ev_edges has been recorded at least once (a wait for it means something)
 };
 
 template <typename T> static PeBufs<T> &bufs(Pe25d *m);
@@ -643,6 +657,10 @@ static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
                             (int)upd_lds_bytes<T>(7, L)) != hipSuccess ||
         hipFuncSetAttribute((const void *)update_rows_kernel_for<T>(7, false), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)upd_lds_bytes<T>(7, L)) != hipSuccess ||
+        hipFuncSetAttribute((const void *)update_rows_kernel_for<T>(5, true), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)upd_lds_bytes<T>(5, L)) != hipSuccess ||
+        hipFuncSetAttribute((const void *)update_rows_kernel_for<T>(5, false), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)upd_lds_bytes<T>(5, L)) != hipSuccess ||
         hipFuncSetAttribute((const void *)update_rows_kernel_for<T>(3, true), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)upd_lds_bytes<T>(3, L)) != hipSuccess ||
         hipFuncSetAttribute((const void *)update_rows_kernel_for<T>(3, false), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -662,6 +680,11 @@ __global__ void spin_kernel(long long ticks) {
     const long long t0 = wall_clock64();          // 100 MHz
     while (wall_clock64() - t0 < ticks) {
     }
+}
+
+// a kernel that does nothing for `us` microseconds (the loopback exchange's stand-in for a transfer time)
+void launch_spin(hipStream_t s, double us) {
+    if (us > 0) hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, s, (long long)(us * 100.0));
 }
 
 hipStream_t concurrent_stream(hipStream_t main, hipStream_t other) {
@@ -714,6 +737,13 @@ hipStream_t concurrent_stream(hipStream_t main, hipStream_t other) {
 }
 
 hipStream_t pe25d_aux_stream(const Pe25d *m) { return m->aux; }
+// gcm_band_run's one join: whatever follows on `s` also follows what the third stream still holds (the own edge
+// rows' column sums of the last stage)
+void pe25d_join_third_stream(Pe25d *m, hipStream_t s) {
+    if (!m->aux2) return;
+    (void)hipEventRecord(m->ev_cs, m->aux2);
+    (void)hipStreamWaitEvent(s, m->ev_cs, 0);
+}
 int pe25d_new_state_set(const Pe25d *m) { return (m->pack_set >= 0 && m->pack_set != 2) ? m->pack_set : m->cur_i; }
 
 Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string *err) {
@@ -785,7 +815,7 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
         bool forced = false;
         if (const char *e = getenv("GCM_PE_LEVEL_SEGMENTS")) { want = atoi(e); forced = true; }
         if (const char *e = getenv("GCM_PE_PIT2D")) m->pit2d = atoi(e) != 0;      // 0: pit from the 3-D fields (pe_pit_kernel)
-        if (const char *e = getenv("GCM_PE_UPDATE_ROWS")) m->upd_rows = atoi(e) == 3 ? 3 : 7;      // rows per workgroup
+        if (const char *e = getenv("GCM_PE_UPDATE_ROWS")) m->upd_rows = atoi(e) == 3 ? 3 : atoi(e) == 5 ? 5 : 7;      // rows per workgroup
         const int cap = std::min(kMaxSeg, std::max(1, L / 4));
         m->nseg = (int)std::max(1L, std::min((long)cap, want));
         // K4 fills the chip with whole columns (a 90-row band: 2 % slower than in two segments) and then
@@ -814,8 +844,16 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
     if (!(no_aux && no_aux[0] == '1')) {
         m->aux = concurrent_stream(main_stream, nullptr);
         if (!m->aux) return bad("second stream");
+        if (const char *e = getenv("GCM_PE_K1_SPLIT")) m->k1_split = atoi(e) != 0;
+        if (!m->wrap && m->k1_split) {
+            m->aux2 = concurrent_stream(main_stream, m->aux);
+            if (!m->aux2) return bad("third stream");
+        }
     }
-    if (hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
+    if (const char *e = getenv("GCM_PE_STOP_EVENTS")) m->stop_events = atoi(e) != 0;
+    if (hipEventCreateWithFlags(&m->ev_k4, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_cs, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_a, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_edges, hipEventDisableTiming) != hipSuccess)
@@ -829,6 +867,12 @@ void pe25d_destroy(Pe25d *m) {
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->ev_a) (void)hipEventDestroy(m->ev_a);
     if (m->ev_edges) (void)hipEventDestroy(m->ev_edges);
+    if (m->ev_cs) (void)hipEventDestroy(m->ev_cs);
+    if (m->ev_k4) (void)hipEventDestroy(m->ev_k4);
+    if (m->aux2) {
+        (void)hipStreamSynchronize(m->aux2);
+        (void)hipStreamDestroy(m->aux2);
+    }
     if (m->aux) {
         (void)hipStreamSynchronize(m->aux);      // (a band's last exchange may still be unpacking)
         (void)hipStreamDestroy(m->aux);
@@ -879,6 +923,8 @@ int pe25d_set(Pe25d *m, bool star, const double *p, const double *u, const doubl
     int rc = xfer(m, star ? 2 : m->cur_i, true, in, nullptr, s, err);
     if (u || v) m->cs_valid[star ? 2 : m->cur_i] = false;
     m->ghost_ready = -1;
+    if (u || v) m->edge_cs_set = -1;
+    m->k4_fork_valid = false;                    // the transposes on the caller's stream: the second stream follows them
     m->last_stage_set = -1;                      // gcm_get_intermediate: the stage state the anchors belong to is gone
     if (rc == GCM_OK) m->star_valid = star;
     return rc;
@@ -911,6 +957,8 @@ static PeArgsT<T> make_args(Pe25d *m, int stage_set, int out_set, double dt) {
     a.part = Bf.part;
     a.part_stride = (long)rows_alloc(m) * m->W;
     a.nseg = m->nseg;
+    a.spu_j0 = a.pit_j0 = -(1 << 30);            // K1: every row of the launch
+    a.spu_j1 = a.pit_j1 = 1 << 30;
     a.inv_dxj = Bf.inv_dxj; a.inv_dxh = Bf.inv_dxh;
     a.sig = Bf.sig; a.dsig = Bf.dsig; a.inv_dsig = Bf.inv_dsig; a.sigb = Bf.sigb; a.sigt = Bf.sigt;
     a.heightmap = Bf.heightmap; a.cor_u = Bf.cor_u; a.cor_v = Bf.cor_v; a.smul = Bf.smul; a.tw = Bf.tw;
@@ -965,7 +1013,7 @@ static void prep_rows(Pe25d *m, const PeArgsT<T> &a, int stage_set, bool p2, int
         c.j1 = m->H + ext;
         m->cs_valid[stage_set] = true;
         fresh = true;
-    } else if (m->nseg_edge > 1) {                   // + the own edge rows (marched in segments: no sums from K4)
+    } else if (m->nseg_edge > 1 && m->edge_cs_set != stage_set) {   // + the own edge rows (marched in segments: no sums from K4)
         c.j0 = -1; c.j1 = kGhost;
         c.jb0 = m->H - kGhost; c.jb1 = m->H + 1;
     } else {
@@ -986,8 +1034,9 @@ static void prep_rows(Pe25d *m, const PeArgsT<T> &a, int stage_set, bool p2, int
 // one Euler stage over rows [j0, j1): state `stage_set` -> `out_set`, base = current.
 // mode 0: everything; mode 1: K1-K3 on all rows + K4 on the two edge rows of either side (the rows
 // a neighbouring band needs); mode 2: K4 on the remaining interior rows.  Modes 1 + 2 == mode 0.
+// chained: the call comes from gcm_band_run's own sequence (nothing but the stage's kernels between two stages on `s`)
 template <typename T>
-static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1, hipStream_t s, int mode) {
+static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1, hipStream_t s, int mode, bool chained) {
     if (j1 <= j0) return;
     PeArgsT<T> a = make_args<T>(m, stage_set, out_set, dt);
     m->last_stage_set = stage_set;
@@ -1033,23 +1082,68 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         a.j0 = j0;
         a.j1 = j1 + ext;
         // ---- chain B: everything that reads the whole stage state, ghost rows included
+        // what chain B follows on the caller's stream: the previous stage's K4 (its own completion, ev_k4, when
+        // nothing else that B reads or overwrites was queued since), else the stream's position now
+        hipEvent_t fork = m->ev_fork;
         if (m->aux) {
-            (void)hipEventRecord(m->ev_fork, s);
-            (void)hipStreamWaitEvent(m->aux, m->ev_fork, 0);
+            if (m->stop_events && m->k4_fork_valid && chained) fork = m->ev_k4;
+            else (void)hipEventRecord(m->ev_fork, s);
+            (void)hipStreamWaitEvent(m->aux, fork, 0);
         }
-        if (m->ghost_ready == stage_set && (!p2 || m->cs_valid[stage_set])) m->ghost_ready = -1;      // queued behind the unpack already
+        const bool ghosts_queued = m->ghost_ready == stage_set && (!p2 || m->cs_valid[stage_set]);
+        if (ghosts_queued) m->ghost_ready = -1;                    // queued behind the unpack already
         else prep_rows<T>(m, a, stage_set, p2, j1, ext, sb);
         static const bool no_loop = getenv("GCM_PE_FILTER_NO_LOOP") != nullptr;        // diagnostic: one workgroup per pair
         const FilterLoopKernel<T> k1 = (m->cfg.filter && W > 1 && !no_loop) ? spu_filter_loop_kernel_for<T>(m->cplan) : nullptr;
-        bool pit_done = false;
-        if (k1) {
+        bool pit_done = false, ev_a_done = false;
+        // (the own edge rows' column sums of this state were queued on the third stream behind the edge rows' K4
+        // of the stage that produced it: everything on the second stream that reads them waits for that)
+        if (m->aux2 && m->edge_cs_set == stage_set) (void)hipStreamWaitEvent(sb, m->ev_cs, 0);
+        // A band inside gcm_band_run (the ghost rows' column sums and anchors are queued behind the unpack already):
+        // K1 is row-local -- spu of row j takes su and sp of row j only, pit of row j the column sums of rows j - 1, j
+        // and sp of rows j - 1 .. j + 1 -- so the band's OWN rows need nothing from the exchange.  They go to a third
+        // stream that waits for the previous stage's K4 only (spu of rows [0, H), pit of rows [2, H - 2]: what the
+        // interior rows' K4 reads), and the second stream keeps the launch for the rows that do need ghost data (spu of
+        // the south ghost row, pit of rows 0, 1, H - 1, H).  The interior rows' K4 then waits for the own-row launch
+        // alone, not for the exchange chain (round 3: 32 us per corrector stage of the N = 8 band of C4).
+        const bool split_k1 = k1 && mode == 1 && m->aux2 && p2 && ghosts_queued && (j1 - j0) >= 2 * kGhost + 3 &&
+                              (m->nseg_edge == 1 || m->edge_cs_set == stage_set);
+        if (split_k1) {
+            const auto launch_k1 = [&](const PeArgsT<T> &c, int rows, hipStream_t st, hipEvent_t stop) {
+                const int groups = std::min(pairs, std::max(1, (3 * m->cus + rows - 1) / rows));
+                const int ppw = (pairs + groups - 1) / groups;
+                const int ny = (pairs + ppw - 1) / ppw;
+                if (stop && m->stop_events)
+                    hipExtLaunchKernelGGL(k1, dim3(rows, ny + 1), dim3(fft_threads), (unsigned)filter_loop_lds_bytes<T>(m), st, nullptr, stop, 0, c, ppw, ny);
+                else
+                    hipLaunchKernelGGL(k1, dim3(rows, ny + 1), dim3(fft_threads), filter_loop_lds_bytes<T>(m), st, c, ppw, ny);
+                if (stop && !m->stop_events) (void)hipEventRecord(stop, st);
+            };
+            (void)hipStreamWaitEvent(m->aux2, fork, 0);
+            if (m->edges_ev_valid) (void)hipStreamWaitEvent(m->aux2, m->ev_edges, 0);   // (the previous stage's edge rows: su, sp of rows 0, 1, H - 2, H - 1)
+            PeArgsT<T> c = a;
+            c.j0 = j0; c.j1 = j1; c.jb0 = c.jb1 = 0;
+            c.pit_j0 = j0 + kGhost; c.pit_j1 = j1 - kGhost + 1;
+            launch_k1(c, j1 - j0, m->aux2, m->ev_a);             // (ev_a: what K4 of the interior rows takes)
+            c = a;
+            c.j0 = j0; c.j1 = j0 + kGhost; c.jb0 = j1 - 1; c.jb1 = j1 + ext;
+            c.spu_j0 = j1; c.spu_j1 = j1 + ext;
+            launch_k1(c, kGhost + 1 + ext, sb, nullptr);
+            (void)hipStreamWaitEvent(sb, m->ev_a, 0);            // the edge rows' partial sums and K4 take spu of own rows
+            pit_done = true;
+        } else if (k1) {
             // all pairs of a row in one workgroup when there are rows enough to fill the chip, else groups;
             // with the 2-D form of pit one more workgroup per row forms pit and p_n (pe_pit2d_row)
             const int rows = a.j1 - a.j0;
             const int groups = std::min(pairs, std::max(1, (3 * m->cus + rows - 1) / rows));
             const int ppw = (pairs + groups - 1) / groups;
             const int ny = (pairs + ppw - 1) / ppw;
-            hipLaunchKernelGGL(k1, dim3(rows, ny + (p2 ? 1 : 0)), dim3(fft_threads), filter_loop_lds_bytes<T>(m), sb, a, ppw, p2 ? ny : -1);
+            if (p2 && m->aux && m->stop_events) {
+                hipExtLaunchKernelGGL(k1, dim3(rows, ny + 1), dim3(fft_threads), (unsigned)filter_loop_lds_bytes<T>(m), sb, nullptr, m->ev_a, 0, a, ppw, ny);
+                ev_a_done = true;
+            } else {
+                hipLaunchKernelGGL(k1, dim3(rows, ny + (p2 ? 1 : 0)), dim3(fft_threads), filter_loop_lds_bytes<T>(m), sb, a, ppw, p2 ? ny : -1);
+            }
             pit_done = p2;
         } else {
             hipLaunchKernelGGL(spu_filter_kernel_for<T>(m->cplan), dim3(a.j1 - a.j0, pairs), dim3(fft_threads), lds, sb, a);
@@ -1060,7 +1154,7 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
             const long tiles = (long)((W + 255) / 256) * (a.j1 - a.j0);
             hipLaunchKernelGGL(pe_pit_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, sb, a);
         }
-        if (m->aux) (void)hipEventRecord(m->ev_a, m->aux);      // (what K4 of the interior rows takes from this chain)
+        if (m->aux && !split_k1 && !ev_a_done) (void)hipEventRecord(m->ev_a, m->aux);      // (what K4 of the interior rows takes from this chain)
         if (mode == 1 && (j1 - j0) > 2 * kGhost && p2 && m->nseg_edge > 1) {
             // a band's edge rows are marched in level segments (see mode 1 below): the partial sums of conv
             // they start from, behind K1 (beside the interior rows' K4 this kernel took 50 us instead of 14)
@@ -1084,13 +1178,18 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         // per-column thermodynamics push it to 187 VGPRs, two waves per SIMD instead of four)
         // (launched with whole waves -- 192 threads for the 144 butterflies of a 1440 row, so that the
         // per-column thermodynamics ahead of the transform fills its lanes -- it takes the same time)
-        hipLaunchKernelGGL(pgf_filter_kernel_for<T>(m->cplan), dim3((unsigned)(8 * ((a.j1 - a.j0 + 7) / 8) * pairs)), dim3(fft_threads), lds, s, a);
+        const bool join = m->aux && mode == 1 && async_edges(m);                     // the edge rows' K4 on B takes pgfu
+        if (join && m->stop_events)
+            hipExtLaunchKernelGGL(pgf_filter_kernel_for<T>(m->cplan), dim3((unsigned)(8 * ((a.j1 - a.j0 + 7) / 8) * pairs)), dim3(fft_threads),
+                                  (unsigned)lds, s, nullptr, m->ev_join, 0, a);
+        else
+            hipLaunchKernelGGL(pgf_filter_kernel_for<T>(m->cplan), dim3((unsigned)(8 * ((a.j1 - a.j0 + 7) / 8) * pairs)), dim3(fft_threads), lds, s, a);
         if (m->aux) {
-            if (mode == 1 && async_edges(m)) (void)hipEventRecord(m->ev_join, s);      // the edge rows' K4 on B takes pgfu
+            if (join && !m->stop_events) (void)hipEventRecord(m->ev_join, s);
             (void)hipStreamWaitEvent(s, m->ev_a, 0);                                   // K4 on A takes spu, pit (and a band's ghost anchors)
         }
     }
-    auto update_rows = [&](int r0, int r1, int rb0, int rb1, hipStream_t st) {   // rows [r0, r1) and [rb0, rb1), one launch
+    auto update_rows = [&](int r0, int r1, int rb0, int rb1, hipStream_t st, hipEvent_t stop = nullptr) {   // rows [r0, r1) and [rb0, rb1), one launch
         const int rows = std::max(0, r1 - r0) + std::max(0, rb1 - rb0);
         if (rows <= 0) return;
         a.j0 = r0;
@@ -1104,13 +1203,15 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         const dim3 gg((unsigned)(8 * rs_per_xcd * ((W + kUpdCols - 1) / kUpdCols)));
         const size_t lds = upd_lds_bytes<T>(Rg, L);
         const bool same = a.u == a.su;
-        hipLaunchKernelGGL(update_rows_kernel_for<T>(Rg, same), gg, dim3(64 * (Rg + 1)), lds, st, a);
+        if (stop && m->stop_events) hipExtLaunchKernelGGL(update_rows_kernel_for<T>(Rg, same), gg, dim3(64 * (Rg + 1)), (unsigned)lds, st, nullptr, stop, 0, a);
+        else hipLaunchKernelGGL(update_rows_kernel_for<T>(Rg, same), gg, dim3(64 * (Rg + 1)), lds, st, a);
     };
     m->cs_valid[out_set] = p2;                   // (modes 1 + 2 together cover the rows)
     const bool split = mode != 0 && (j1 - j0) > 2 * kGhost;
     if (mode == 0) {
         tick(m, s);
-        update_rows(j0, j1, 0, 0, s);
+        update_rows(j0, j1, 0, 0, s, m->ev_k4);
+        m->k4_fork_valid = m->stop_events && !(m->ev && m->ev_used);       // (timing runs put records behind the kernel)
         tick(m, s);
     } else if (mode == 1) {
         // the rows the neighbours wait for (an unsplittable, tiny band: all of them).  With send
@@ -1139,21 +1240,45 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
             std::string err;
             (void)pe25d_halo_segments(m, true, 0, m->send_buf[0], &c, &err);
             (void)pe25d_halo_segments(m, true, 1, m->send_buf[1], &c, &err);
-            launch_seg_copy(c, se);
-            (void)hipEventRecord(m->ev_edges, se);
+            if (m->stop_events) launch_seg_copy(c, se, m->ev_edges);
+            else {
+                launch_seg_copy(c, se);
+                (void)hipEventRecord(m->ev_edges, se);
+            }
             m->edges_pending = true;
+            m->edges_ev_valid = true;
+            if (m->aux2 && split && p2 && m->nseg_edge > 1) {
+                // the edge rows were marched in level segments and left no column sums: formed here, on the third
+                // stream, as soon as the rows exist -- beside the interior rows still at work, off every chain of the
+                // next stage (which read them: pit of rows 0 .. 2 and H - 2 .. H)
+                (void)hipStreamWaitEvent(m->aux2, m->ev_edges, 0);
+                PeArgsT<T> cc = make_args<T>(m, out_set, out_set, dt);
+                cc.j0 = j0; cc.j1 = j0 + kGhost; cc.jb0 = j1 - kGhost; cc.jb1 = j1;
+                if (m->stop_events)
+                    hipExtLaunchKernelGGL(pe_colsum_kernel<T>, dim3((unsigned)((W + 255) / 256) * (2 * kGhost)), dim3(256), 0, m->aux2, nullptr, m->ev_cs, 0, cc);
+                else {
+                    hipLaunchKernelGGL(pe_colsum_kernel<T>, dim3((unsigned)((W + 255) / 256) * (2 * kGhost)), dim3(256), 0, m->aux2, cc);
+                    (void)hipEventRecord(m->ev_cs, m->aux2);
+                }
+                m->edge_cs_set = out_set;
+            }
         }
     } else {
-        if (split) update_rows(j0 + kGhost, j1 - kGhost, 0, 0, s);
+        if (split) {
+            update_rows(j0 + kGhost, j1 - kGhost, 0, 0, s, m->ev_k4);
+            m->k4_fork_valid = m->stop_events;
+        }
         // whatever follows on the caller's stream also follows the edge rows
         if (async_edges(m) && m->edges_pending) (void)hipStreamWaitEvent(s, m->ev_edges, 0);
         m->edges_pending = false;
     }
 }
 
-static void half(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1, hipStream_t s, int mode = 0) {
-    if (m->f32) half_t<float>(m, stage_set, out_set, dt, j0, j1, s, mode);
-    else half_t<double>(m, stage_set, out_set, dt, j0, j1, s, mode);
+static void half(Pe25d *m, int stage_set, int out_set, double dt, int j0, int j1, hipStream_t s, int mode = 0, bool chained = false) {
+    // (a single domain's stages follow one another on `s` with nothing between them that chain B must wait for)
+    const bool ch = chained || (mode == 0 && m->wrap);
+    if (m->f32) half_t<float>(m, stage_set, out_set, dt, j0, j1, s, mode, ch);
+    else half_t<double>(m, stage_set, out_set, dt, j0, j1, s, mode, ch);
 }
 
 // gcm_band_run, right behind the unpack on the second stream: the ghost rows that have just arrived belong to
@@ -1254,7 +1379,7 @@ int pe25d_step_part(Pe25d *m, int part, double dt, hipStream_t s, std::string *e
 //   phase 3  corrector K4 interior rows, then the swap
 // gcm_halo_pack after phase 0 / 2 packs the rows just produced; gcm_halo_unpack after phase 1 / 3
 // fills the ghost rows of the predicted / the new current state.
-int pe25d_step_phase(Pe25d *m, int phase, double dt, hipStream_t s, std::string *err) {
+int pe25d_step_phase(Pe25d *m, int phase, double dt, hipStream_t s, std::string *err, bool chained) {
     if (m->wrap) {
         *err = "step_phase: handle is not a latitude band";
         return GCM_ERR_STATE;
@@ -1263,17 +1388,17 @@ int pe25d_step_phase(Pe25d *m, int phase, double dt, hipStream_t s, std::string 
         case 0:
             m->star_valid = true;
             m->pack_set = 2;
-            half(m, m->cur_i, 2, dt, 0, m->H, s, 1);
+            half(m, m->cur_i, 2, dt, 0, m->H, s, 1, chained);
             break;
         case 1:
-            half(m, m->cur_i, 2, dt, 0, m->H, s, 2);
+            half(m, m->cur_i, 2, dt, 0, m->H, s, 2, chained);
             break;
         case 2:
             m->pack_set = 1 - m->cur_i;
-            half(m, 2, 1 - m->cur_i, dt, 0, m->H, s, 1);
+            half(m, 2, 1 - m->cur_i, dt, 0, m->H, s, 1, chained);
             break;
         case 3:
-            half(m, 2, 1 - m->cur_i, dt, 0, m->H, s, 2);
+            half(m, 2, 1 - m->cur_i, dt, 0, m->H, s, 2, chained);
             m->cur_i = 1 - m->cur_i;
             m->star_valid = false;
             m->pack_set = -1;
@@ -1300,6 +1425,7 @@ int pe25d_set_halo_buffers(Pe25d *m, void *north, void *south, hipStream_t s, st
     }
     (void)hipStreamSynchronize(s);
     if (m->aux) (void)hipStreamSynchronize(m->aux);
+    if (m->aux2) (void)hipStreamSynchronize(m->aux2);
     m->send_buf[0] = north;
     m->send_buf[1] = south;
     m->edges_pending = false;
@@ -1386,6 +1512,7 @@ static int filter_field_t(Pe25d *m, int nlev, const double *in, double *out, hip
     const int W = m->W, H = m->H;
     const size_t bytes = sizeof(double) * (size_t)nlev * H * W;
     m->last_stage_set = -1;                      // spu, pgfu and pit are scratch here: the parity tap has nothing to return
+    m->k4_fork_valid = false;
     hipError_t e = hipMemcpyAsync(m->stage3, in, bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(pe_to_device_kernel<T>, dim3(1024), dim3(256), 0, s, B.pgfu, m->stage3, W, H, nlev);
@@ -1523,6 +1650,9 @@ static int radiation_launch(Pe25d *m, int set, int j0, int j1, int jb0, int jb1,
     r.albedo = albedo; r.dt = dt; r.apply = apply ? 1 : 0;
     if (apply && !keep_ghosts) m->ghost_ready = -1;        // theta changes in place
     m->last_stage_set = -1;                                // gcm_get_intermediate: theta changed, or pgfu / pit hold the tendencies
+    // the diagnostic form writes pgfu / pit on `s`, and a band's explicit solar_timestep changes the ghost rows' theta
+    // there: the next stage's chain B (K1 + pit, the ghost rows' anchors) follows the stream's position, not just the last K4
+    if (!(apply && (keep_ghosts || m->wrap))) m->k4_fork_valid = false;
     {
         const dim3 gg((W + kRadThreads - 1) / kRadThreads, nrows);
         T *th = B.st[set][GCM_T];

@@ -6,14 +6,13 @@
 
 namespace gcm {
 
-// one workgroup per row j of [j0, j1): pit and p_n = p - pit dt (dynamics.py:38-40,194)
+// one workgroup per row j: pit and p_n = p - pit dt (dynamics.py:38-40,194)
 template <typename T, int MAXR, unsigned MASK = 0>
-__device__ __forceinline__ void pe_pit2d_row(const PeArgsT<T> &a, typename Vec2<T>::type *x, const int row) {
+__device__ __forceinline__ void pe_pit2d_row(const PeArgsT<T> &a, typename Vec2<T>::type *x, const int j) {
     using V = typename Vec2<T>::type;
     const Idx ix{a.W, a.H, a.L, a.wrap};
     const int W = a.W;
     T *fx = (T *)(x + (MAXR > 0 ? 1 : 2) * W);                  // the filtered row, after the transform's workspace
-    const int j = a.j0 + row;
     const int jg = wrapi(a.row0 + j, a.Hg);
     const T *sp = a.sp + ix.r2(j);
     const T *cu = a.scs_u + ix.r2(j);

@@ -55,6 +55,7 @@ struct SegCopy {          // up to (5 fields + the ground temperature) x 2 sides
     long n[12];
     int nseg;
 };
-void launch_seg_copy(const SegCopy &c, hipStream_t s);
+// stop: an event signalled by the copy kernel's own completion (hipExtLaunchKernelGGL), or null
+void launch_seg_copy(const SegCopy &c, hipStream_t s, hipEvent_t stop = nullptr);
 
 }  // namespace gcm

@@ -12,6 +12,8 @@
 //           run in one launch, so every field is read once and written once per step.
 #include "sw2d_kernels.h"
 
+#include <hip/hip_ext.h>
+
 #include <cmath>
 #include <cstdlib>
 
@@ -619,13 +621,17 @@ __global__ void seg_copy_kernel(SegCopy c) {
         dst[i] = src[i];
 }
 
-void launch_seg_copy(const SegCopy &c, hipStream_t s) {
+void launch_seg_copy(const SegCopy &c, hipStream_t s, hipEvent_t stop) {
     long mx = 0;
     for (int k = 0; k < c.nseg; ++k) mx = c.n[k] > mx ? c.n[k] : mx;
-    if (mx <= 0 || c.nseg <= 0) return;
+    if (mx <= 0 || c.nseg <= 0) {
+        if (stop) (void)hipEventRecord(stop, s);
+        return;
+    }
     int blocks = (int)((mx + 255) / 256);
     if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(seg_copy_kernel, dim3(blocks, c.nseg), dim3(256), 0, s, c);
+    if (stop) hipExtLaunchKernelGGL(seg_copy_kernel, dim3(blocks, c.nseg), dim3(256), 0, s, nullptr, stop, 0, c);
+    else hipLaunchKernelGGL(seg_copy_kernel, dim3(blocks, c.nseg), dim3(256), 0, s, c);
 }
 
 }  // namespace gcm

@@ -137,6 +137,13 @@ class RcclP2P:
         if not bool((got == float(north)).all()):
             raise RcclError("rccl self-check: rank %d received %r from rank %d" % (self.rank, got[:2].tolist(), north))
 
+    def count(self):
+        """ncclCommCount: the number of ranks this communicator really has (bench.py prints it in the N > 1 line)"""
+        n = C.c_int(-1)
+        self.lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        self._check(self.lib.ncclCommCount(self.comm, C.byref(n)))
+        return n.value
+
     def close(self):
         if self.comm:
             self.lib.ncclCommDestroy(self.comm)

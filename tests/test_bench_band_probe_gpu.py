@@ -23,6 +23,10 @@ class _OneRank:
     def all_reduce(self, t, op=None):
         return t
 
+    def all_gather(self, out, t):
+        for o in out:
+            o.copy_(t)
+
 
 def test_run_workload_band_path_and_overlap_probe(monkeypatch):
     import torch
@@ -42,6 +46,11 @@ def test_run_workload_band_path_and_overlap_probe(monkeypatch):
     probe = res["band_overlap_probe_ms_per_step"]
     assert probe["chosen"] in ("plain", "overlap") and probe["plain"] > 0 and probe["overlap"] > 0
     assert "diagnostics" in res and res["diagnostics"]["band_ms_per_step_local_exchange"] > 0
+    # what makes the N > 1 line readable on its own
+    assert res["roofline"]["peak"] == 2 * 8000.0 and 0 < res["roofline"]["frac"] < 1
+    assert len(res["band_ms_per_step"]["per_rank"]) == 2 and res["band_ms_per_step"]["max"] > 0
+    assert res["exchange_bytes"]["message_bytes"] == 5 * 8 * 4096 * 8 and res["exchange_bytes"]["exchanges_per_step"] == 0.25
+    assert "rccl_ranks" in res
 
 
 def test_run_workload_pe25d_band_path(monkeypatch):

@@ -1,12 +1,20 @@
 // What stream-ordering primitives cost between two small kernels on MI355X (the band step of GCM_PE25D is a
 // chain of small kernels on two streams): hipcc --offload-arch=gfx950 -O2 sync_cost.hip -o sync_cost
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <vector>
 __global__ void spin(long long ticks) {
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) {}
 }
+// does a wait for a stopEvent really wait for the kernel?  a: spin, then write n; b: read the cell at its very start
+__global__ void spin_then_set(long long ticks, int *cell, int v) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+    if (threadIdx.x == 0) { __threadfence_system(); *cell = v; }
+}
+__global__ void read_at_start(const int *cell, int *out, int n) { if (threadIdx.x == 0) out[n] = *(volatile const int *)cell; }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 int main() {
     hipStream_t a, b;
@@ -51,6 +59,49 @@ int main() {
     run("+ ping-pong: kernel on a, then kernel on b that waits for it, then back", [&](int) {
         (void)hipEventRecord(ev, a); (void)hipStreamWaitEvent(b, ev, 0); hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, b, T);
         (void)hipEventRecord(done_b, b); (void)hipStreamWaitEvent(a, done_b, 0); });
+    // round 4: the kernel's OWN completion signal as the event (hipExtLaunchKernelGGL's stopEvent) instead of a
+    // record packet behind it
+    {
+        auto run_ext = [&](const char *name, bool fork) -> int {
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipStreamSynchronize(a)); CK(hipStreamSynchronize(b));
+                CK(hipEventRecord(e0, a));
+                for (int n = 0; n < N; ++n) {
+                    hipExtLaunchKernelGGL(spin, dim3(1), dim3(64), 0, a, nullptr, ev, 0, T);
+                    if (fork) { (void)hipStreamWaitEvent(b, ev, 0); hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, b, T); }
+                }
+                CK(hipEventRecord(e1, a));
+                CK(hipEventSynchronize(e1));
+                CK(hipStreamSynchronize(b));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep == 1) printf("%-72s %7.2f us per iteration (kernel itself 5.0)\n", name, ms * 1e3 / N);
+            }
+            return 0;
+        };
+        run_ext("kernels launched with a stopEvent (hipExtLaunchKernelGGL), no record", false);
+        run_ext("the same, stream b waits for that stopEvent and runs a kernel (fork)", true);
+    }
+    {
+        // correctness of the stopEvent dependency: 200 rounds, b must see the value a's kernel wrote at its END
+        int *cell = nullptr, *out = nullptr;
+        CK(hipMalloc(&cell, sizeof(int))); CK(hipMalloc(&out, 256 * sizeof(int)));
+        CK(hipMemset(cell, 0, sizeof(int))); CK(hipMemset(out, 0xff, 256 * sizeof(int)));
+        hipEvent_t back;
+        CK(hipEventCreateWithFlags(&back, hipEventDisableTiming));
+        for (int n = 0; n < 200; ++n) {
+            hipExtLaunchKernelGGL(spin_then_set, dim3(1), dim3(64), 0, a, nullptr, ev, 0, 2000LL, cell, n + 1);     // 20 us
+            CK(hipStreamWaitEvent(b, ev, 0));
+            hipExtLaunchKernelGGL(read_at_start, dim3(1), dim3(64), 0, b, nullptr, back, 0, (const int *)cell, out, n);
+            CK(hipStreamWaitEvent(a, back, 0));                   // (a's next write must not overtake b's read)
+        }
+        CK(hipStreamSynchronize(a)); CK(hipStreamSynchronize(b));
+        int h[200];
+        CK(hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int n = 0; n < 200; ++n) bad += h[n] != n + 1;
+        printf("stopEvent dependency check: %d of 200 reads on b saw a stale value (0 = the wait is a real wait)\n", bad);
+    }
     run("+ hipMemcpyAsync D2D 2 MB between", [&](int) {
         static void *p = nullptr, *q = nullptr;
         if (!p) { (void)hipMalloc(&p, 2 << 20); (void)hipMalloc(&q, 2 << 20); }
