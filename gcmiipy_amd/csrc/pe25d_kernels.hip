@@ -811,7 +811,11 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
         m->cus = cus;
         const double rounds = (double)((W + kUpdCols - 1) / kUpdCols) * m->H / (8.0 * cus);
         long want = (long)std::ceil(1.5 / std::max(rounds, 1e-3));
-        m->upd_rows = m->H <= 256 ? 3 : 7;
+        // fp32: 153 VGPRs and 34 KB of tiles per 3-row workgroup let THREE of them share a CU (three waves per SIMD; the
+        // 7-row form holds one 8-wave workgroup, two waves per SIMD): c4_f32 1.214 -> 1.126 ms per step (round 4, A/B
+        // on one box; 5-row groups, 6 waves, place only one workgroup per CU and take 1.44).  fp64 (215 / 231 VGPRs)
+        // stays at two waves per SIMD either way: 3-row groups only where the band is short.
+        m->upd_rows = (m->H <= 256 || m->f32) ? 3 : 7;
         bool forced = false;
         if (const char *e = getenv("GCM_PE_LEVEL_SEGMENTS")) { want = atoi(e); forced = true; }
         if (const char *e = getenv("GCM_PE_PIT2D")) m->pit2d = atoi(e) != 0;      // 0: pit from the 3-D fields (pe_pit_kernel)
@@ -1062,7 +1066,7 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
     hipStream_t sb = m->aux ? m->aux : s;
     // pe_geopot_kernel over the rows of `c` ([j0, j1) and [jb0, jb1)); c.geo_j0 / geo_j1: the rows it forms phi
     // for, c.cs_rows: it also forms the column sums of all its rows
-    const auto geopot = [&](const PeArgsT<T> &c, hipStream_t st) {
+    const auto geopot = [&](const PeArgsT<T> &c, hipStream_t st, hipEvent_t stop = nullptr) {
         const int rows = (c.j1 - c.j0) + (c.jb1 - c.jb0);
         if (rows <= 0) return;
         const long tiles = (long)((W + kColThreads - 1) / kColThreads) * rows;
@@ -1073,11 +1077,19 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
             else if (L <= 40) hipLaunchKernelGGL((pe_geopot_kernel<T, 40, true>), gg, dim3(kColThreads), 0, st, c);
             else hipLaunchKernelGGL((pe_geopot_kernel<T, 0, true>), gg, dim3(kColThreads), park, st, c);
         } else {
-            if (L <= 24) hipLaunchKernelGGL((pe_geopot_kernel<T, 24>), gg, dim3(kColThreads), 0, st, c);
-            else if (L <= 40) hipLaunchKernelGGL((pe_geopot_kernel<T, 40>), gg, dim3(kColThreads), 0, st, c);
-            else hipLaunchKernelGGL((pe_geopot_kernel<T, 0>), gg, dim3(kColThreads), park, st, c);
+            void (*kern)(PeArgsT<T>) = L <= 24 ? pe_geopot_kernel<T, 24> : L <= 40 ? pe_geopot_kernel<T, 40> : pe_geopot_kernel<T, 0>;
+            const unsigned dyn = L <= 40 ? 0u : (unsigned)park;
+            if (stop) hipExtLaunchKernelGGL(kern, gg, dim3(kColThreads), dyn, st, nullptr, stop, 0, c);
+            else hipLaunchKernelGGL(kern, gg, dim3(kColThreads), dyn, st, c);
         }
     };
+    const bool split = mode != 0 && (j1 - j0) > 2 * kGhost;
+    // (Round 4, built and rejected: the edge rows' K3 as a launch of its own on chain B right behind K2a, so that their
+    // K4, the pack and the exchange start before the interior rows' K4 takes the chip.  Four rows are 48 workgroups of
+    // five dependent LDS passes: 30-60 us on a chain that already holds K1's ghost-row launch and the partial sums, and
+    // the N = 8 band got 4 % slower with no exchange time and 10 % slower with 40 us of it
+    // (profiles/r04/ab_band_edge_k3_on_chain_b.txt: `base` = with it).)
+    bool split_k1 = false;
     if (mode != 2) {
         a.j0 = j0;
         a.j1 = j1 + ext;
@@ -1106,7 +1118,7 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         // interior rows' K4 reads), and the second stream keeps the launch for the rows that do need ghost data (spu of
         // the south ghost row, pit of rows 0, 1, H - 1, H).  The interior rows' K4 then waits for the own-row launch
         // alone, not for the exchange chain (round 3: 32 us per corrector stage of the N = 8 band of C4).
-        const bool split_k1 = k1 && mode == 1 && m->aux2 && p2 && ghosts_queued && (j1 - j0) >= 2 * kGhost + 3 &&
+        split_k1 = k1 && mode == 1 && m->aux2 && p2 && ghosts_queued && (j1 - j0) >= 2 * kGhost + 3 &&
                               (m->nseg_edge == 1 || m->edge_cs_set == stage_set);
         if (split_k1) {
             const auto launch_k1 = [&](const PeArgsT<T> &c, int rows, hipStream_t st, hipEvent_t stop) {
@@ -1129,8 +1141,7 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
             c.j0 = j0; c.j1 = j0 + kGhost; c.jb0 = j1 - 1; c.jb1 = j1 + ext;
             c.spu_j0 = j1; c.spu_j1 = j1 + ext;
             launch_k1(c, kGhost + 1 + ext, sb, nullptr);
-            (void)hipStreamWaitEvent(sb, m->ev_a, 0);            // the edge rows' partial sums and K4 take spu of own rows
-            pit_done = true;
+            pit_done = true;                                     // (chain B waits for ev_a below, ahead of the edge rows' partial sums)
         } else if (k1) {
             // all pairs of a row in one workgroup when there are rows enough to fill the chip, else groups;
             // with the 2-D form of pit one more workgroup per row forms pit and p_n (pe_pit2d_row)
@@ -1155,15 +1166,6 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
             hipLaunchKernelGGL(pe_pit_kernel<T>, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(256), 0, sb, a);
         }
         if (m->aux && !split_k1 && !ev_a_done) (void)hipEventRecord(m->ev_a, m->aux);      // (what K4 of the interior rows takes from this chain)
-        if (mode == 1 && (j1 - j0) > 2 * kGhost && p2 && m->nseg_edge > 1) {
-            // a band's edge rows are marched in level segments (see mode 1 below): the partial sums of conv
-            // they start from, behind K1 (beside the interior rows' K4 this kernel took 50 us instead of 14)
-            PeArgsT<T> c = a;
-            c.nseg = m->nseg_edge;
-            c.j0 = j0; c.j1 = j0 + kGhost + 1;            // (K4 of row j also takes the sums of row j + 1)
-            c.jb0 = j1 - kGhost; c.jb1 = j1 + 1;
-            hipLaunchKernelGGL(pe_part_kernel<T>, dim3((unsigned)((W + 255) / 256) * (2 * kGhost + 2)), dim3(256), 0, sb, c);
-        }
         // ---- chain A: geopotential of the own rows, then the filtered pressure-gradient force
         a.j0 = j0;
         a.j1 = j1;
@@ -1207,7 +1209,6 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         else hipLaunchKernelGGL(update_rows_kernel_for<T>(Rg, same), gg, dim3(64 * (Rg + 1)), lds, st, a);
     };
     m->cs_valid[out_set] = p2;                   // (modes 1 + 2 together cover the rows)
-    const bool split = mode != 0 && (j1 - j0) > 2 * kGhost;
     if (mode == 0) {
         tick(m, s);
         update_rows(j0, j1, 0, 0, s, m->ev_k4);
@@ -1221,6 +1222,16 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         const bool as = async_edges(m);
         hipStream_t se = as && m->aux ? m->aux : s;
         if (as && m->aux) (void)hipStreamWaitEvent(m->aux, m->ev_join, 0);
+        if (split_k1) (void)hipStreamWaitEvent(se, m->ev_a, 0);      // the edge rows' partial sums and K4 take spu of own rows
+        if (split && p2 && m->nseg_edge > 1) {
+            // a band's edge rows are marched in level segments (below): the partial sums of conv they start from,
+            // behind K1 on chain B (beside the interior rows' K4 this kernel took 50 us instead of 14)
+            PeArgsT<T> c = a;
+            c.nseg = m->nseg_edge;
+            c.j0 = j0; c.j1 = j0 + kGhost + 1;            // (K4 of row j also takes the sums of row j + 1)
+            c.jb0 = j1 - kGhost; c.jb1 = j1 + 1;
+            hipLaunchKernelGGL(pe_part_kernel<T>, dim3((unsigned)((W + 255) / 256) * (2 * kGhost + 2)), dim3(256), 0, se, c);
+        }
         if (split && p2 && m->nseg_edge > 1) {
             // the edge rows in level segments: a quarter of the chain of dependent levels, so the pack
             // and the exchange start while the interior rows are still at work
