@@ -23,6 +23,7 @@ def clear_cache():
     for cache in (matsuno_c_grid._cache, dynamics._cache):
         while cache:
             cache.popitem()[1].close()
+    _lib.lib.gcm_ops_release_scratch()      # the operator entry points' device scratch of this thread
 
 
 __all__ = ["Core", "GcmError", "device_count", "clear_cache"]

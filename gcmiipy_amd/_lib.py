@@ -127,6 +127,7 @@ SYMBOLS = {
     "gcm_pe1d_op": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gcm_array_stats": (C.c_int, [C.c_void_p, C.c_long, C.c_long, C.c_void_p]),
     "gcm_ops_last_error": (C.c_char_p, []),
+    "gcm_ops_release_scratch": (C.c_int, []),
     "gcm_time_steps": (C.c_int, [_H, C.c_int, C.c_double, _dp, _dp]),
 }
 

@@ -38,7 +38,8 @@ struct DevArena {
             }
         }
         size_t cap = bytes;
-        if (!blocks.empty() && 2 * blocks.back().cap > cap) cap = 2 * blocks.back().cap;
+        // (doubling only while the arena is small: an operand of a production-size field is taken at its own size)
+        if (!blocks.empty() && 2 * blocks.back().cap > cap && blocks.back().cap < kKeepCap) cap = 2 * blocks.back().cap;
         if (cap < ((size_t)1 << 20)) cap = (size_t)1 << 20;
         void *d = nullptr;
         if (hipMalloc(&d, cap) != hipSuccess) {
@@ -48,8 +49,17 @@ struct DevArena {
         blocks.push_back(Block{(char *)d, cap, bytes});
         return d;
     }
-    // end of a call: everything is handed back; several blocks become one of their combined size
+    // end of a call: everything is handed back; several blocks become one of their combined size -- unless that
+    // is more than kKeepCap: a call on a production-size field (2880x1440x40 fp64: 1.3 GB per operand) does not pin
+    // gigabytes of HBM for the rest of the thread's life, it allocates again next time
+    static constexpr size_t kKeepCap = (size_t)256 << 20;
     void reset() {
+        size_t held = 0;
+        for (const Block &b : blocks) held += b.cap;
+        if (held > kKeepCap) {
+            release();
+            return;
+        }
         if (blocks.size() > 1) {
             size_t total = 0;
             for (const Block &b : blocks) total += b.cap;

@@ -324,6 +324,11 @@ extern "C" {
 
 const char *gcm_ops_last_error(void) { return g_ops_error.c_str(); }
 
+int gcm_ops_release_scratch(void) {
+    gcm::thread_arena().release();
+    return GCM_OK;
+}
+
 int gcm_advect2d(int scheme, int axes, int finite, int width, int height, int nsteps, double dt,
                  double dx0, double dx1, const double *V, const double *q_in, double *q_out) {
     if (!V || !q_in || !q_out || width < 1 || height < 1 || nsteps < 0 || !(dx0 > 0) || !(dx1 > 0))

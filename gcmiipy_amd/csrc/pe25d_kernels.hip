@@ -50,6 +50,9 @@ __device__ __forceinline__ T column_sum(const T *col, const T *dsig, int L, int 
 // park, so the occupancy is not limited by it); LMAX == 0: any L, stp parked in LDS
 // CS: the launch also forms the column sums of its rows (a band's ghost rows; a template parameter, because the
 // mere presence of that code in the kernel cost the plain instantiation 40 % of its speed)
+// (Round 4, priced with a timing proxy and not built: this kernel also emitting pgu + phiu of every level, so that K3
+// becomes a pure filter -- K2a 74.8 -> 116 us, K3 171 -> the 120 us K1 takes for the same traffic: -1.2 % of the step,
+// profiles/r04/ab_k2a_emits_pgu_phiu_proxy.txt.)
 template <typename T, int LMAX = 0, bool CS = false>
 __global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
     __shared__ double tab[kExnerTabDoubles];

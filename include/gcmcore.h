@@ -402,6 +402,11 @@ typedef enum {
 } gcm_pe1d_op_kind;
 int gcm_pe1d_op(int kind, int n, double dx, const double *x0, const double *x1, const double *x2, double *out);
 const char *gcm_ops_last_error(void);
+/* The stand-alone operator entry points above (host arrays in, host arrays out: gcm_sw2d_op, gcm_pe25d_op,
+ * gcm_pe1d_op, gcm_flux_limiter, gcm_pgf2d, gcm_advect2d) carve their device operands from a scratch arena the
+ * calling thread keeps between calls (at most 256 MB: a call that needed more hands everything back when it
+ * ends).  This frees the calling thread's arena now.  Returns 0.                                          */
+int gcm_ops_release_scratch(void);
 
 /* Timing helper for bench.py: runs nsteps steps bracketed by HIP events on the
  * handle's stream; returns elapsed milliseconds in *ms and, in *kernel_ms_avg,

@@ -262,6 +262,10 @@ int main() {
         // row pitch: arrays re-based at (n + slack) doubles apart so that a padded pitch fits
         for (int pad : {0, 16, 32, 512}) {   // H * pad <= slack
             const int P = W + pad;
+            if ((long)H * pad > slack) {          // a pitch the arrays were not spaced for would run past them: say so, do not launch
+                printf("strip march, row pitch = 4096 + %4d doubles: skipped (H * pad = %ld > slack = %ld doubles)\n", pad, (long)H * pad, slack);
+                continue;
+            }
             for (int f = 0; f < NF; ++f) { s[f] = sall + f * (n + slack); d[f] = dall + f * (n + slack); }
             CK(hipMemcpy(ds, s.data(), sizeof(double *) * NF, hipMemcpyHostToDevice));
             CK(hipMemcpy(dd, d.data(), sizeof(double *) * NF, hipMemcpyHostToDevice));
