@@ -34,7 +34,7 @@ L2_BYTES = 32 * 2 ** 20
 SETTLE_S = float(os.environ.get("GCM_BENCH_SETTLE_S", "0.15"))   # untimed pre-conditioning before warm-up (see run_workload)
 MIN_TIMED_S = float(os.environ.get("GCM_BENCH_MIN_TIMED_S", "0.5"))   # the K-step block is repeated until this much is timed
 MAX_BLOCKS = 400
-PROFILE_ROUND = "r03"     # profiles/<round>/traffic.json: PMC passes of this same command (tools/tools_prof.sh)
+PROFILE_ROUND = "r04"     # profiles/<round>/traffic.json: PMC passes of this same command (tools/tools_prof.sh)
 
 WORKLOADS = {
     # name: (description, H, W, L, model, tracer, bytes per cell-update = 2 * fields * 8, dt)

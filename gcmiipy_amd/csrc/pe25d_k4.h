@@ -374,7 +374,6 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
 template <typename T>
 FilterKernel<T> update_rows_kernel_for(int rows_per_group, bool same) {
     if (rows_per_group == 7) return same ? pe_update_rows_kernel<T, 7, true> : pe_update_rows_kernel<T, 7, false>;
-    if (rows_per_group == 5) return same ? pe_update_rows_kernel<T, 5, true> : pe_update_rows_kernel<T, 5, false>;
     return same ? pe_update_rows_kernel<T, 3, true> : pe_update_rows_kernel<T, 3, false>;
 }
 

@@ -660,10 +660,6 @@ static const char *alloc_all(Pe25d *m, const gcm_config &cfg) {
                             (int)upd_lds_bytes<T>(7, L)) != hipSuccess ||
         hipFuncSetAttribute((const void *)update_rows_kernel_for<T>(7, false), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)upd_lds_bytes<T>(7, L)) != hipSuccess ||
-        hipFuncSetAttribute((const void *)update_rows_kernel_for<T>(5, true), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)upd_lds_bytes<T>(5, L)) != hipSuccess ||
-        hipFuncSetAttribute((const void *)update_rows_kernel_for<T>(5, false), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)upd_lds_bytes<T>(5, L)) != hipSuccess ||
         hipFuncSetAttribute((const void *)update_rows_kernel_for<T>(3, true), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)upd_lds_bytes<T>(3, L)) != hipSuccess ||
         hipFuncSetAttribute((const void *)update_rows_kernel_for<T>(3, false), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -822,7 +818,7 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
         bool forced = false;
         if (const char *e = getenv("GCM_PE_LEVEL_SEGMENTS")) { want = atoi(e); forced = true; }
         if (const char *e = getenv("GCM_PE_PIT2D")) m->pit2d = atoi(e) != 0;      // 0: pit from the 3-D fields (pe_pit_kernel)
-        if (const char *e = getenv("GCM_PE_UPDATE_ROWS")) m->upd_rows = atoi(e) == 3 ? 3 : atoi(e) == 5 ? 5 : 7;      // rows per workgroup
+        if (const char *e = getenv("GCM_PE_UPDATE_ROWS")) m->upd_rows = atoi(e) == 3 ? 3 : 7;      // rows per workgroup
         const int cap = std::min(kMaxSeg, std::max(1, L / 4));
         m->nseg = (int)std::max(1L, std::min((long)cap, want));
         // K4 fills the chip with whole columns (a 90-row band: 2 % slower than in two segments) and then
