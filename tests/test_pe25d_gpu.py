@@ -556,3 +556,51 @@ def test_hot_path_intermediates_vs_oracle_1440_columns(g):
     for a, b, k in zip(c.get_state(), stage_state, "puvtq"):
         assert rel_err(a, b) < TOL, k
     c.close()
+
+
+def test_set_physics_is_the_explicit_loop(g):
+    """gcm_set_physics: every step of gcm_step = matsuno_timestep + solar_timestep at the handle's clock, clock += dt
+    (the loop of no_limits_2_5d.run_model, :229-234, with the physics below full_timestep's early return) -- bit for
+    bit the explicit sequence of calls, which golden g13 and the 2880x1440x40 strips pin against the reference; and
+    the error paths"""
+    from gcmiipy_amd import geometry
+    from gcmiipy_amd.core import GcmError
+    d = golden("g8_pe25d")
+    geom = geometry.gen_geometry(24, 36, 9, sig_func=geometry.manabe_sig)
+    ic = [d["dense_%s0" % k] for k in "puvtq"]
+    gt = 288.0 + np.random.default_rng(3).standard_normal((24, 36))
+    utc0, dt = 4 * 3600.0, 300.0
+    for dtype in ("f64", "f32"):
+        a = g.Core(g._lib.PE25D, 36, 24, 9, geom=geom, dtype=dtype)
+        a.set_state(*ic)
+        a.set_ground(gt)
+        utc = utc0
+        for n in range(3):
+            a.step(1, dt)
+            a.solar_step(geom, dt, utc)
+            utc += dt
+        want, want_gt = a.get_state(), a.get_ground()
+        a.close()
+        b = g.Core(g._lib.PE25D, 36, 24, 9, geom=geom, dtype=dtype)
+        b.set_state(*ic)
+        with pytest.raises(GcmError, match="no physics registered"):
+            b.utc()
+        b.set_physics(geom, utc0)
+        with pytest.raises(GcmError, match="ground temperature first"):
+            b.step(1, dt)                                  # the physics needs gcm_set_ground
+        b.set_ground(gt)
+        b.step(2, dt)
+        b.step(1, dt)
+        assert b.utc() == utc
+        for x, y in zip(b.get_state(), want):
+            assert np.array_equal(x, y), dtype
+        assert np.array_equal(b.get_ground(), want_gt)
+        b.set_physics(None)                                # dynamics only again
+        t0 = b.get_ground()
+        b.step(1, dt)
+        assert np.array_equal(b.get_ground(), t0)
+        b.close()
+    sw = g.Core(g._lib.SW2D, 32, 16, dx=300e3)
+    with pytest.raises(GcmError, match="GCM_PE25D only"):
+        sw.set_physics(geometry.gen_geometry(16, 32, 2, sig_func=geometry.manabe_sig), 0.0)
+    sw.close()
