@@ -1,6 +1,6 @@
 // Device-side definitions shared by the translation units of GCM_PE25D (pe25d_kernels.hip = host side
 // and column kernels; pe25d_k1_*.hip, pe25d_k3_*.hip, pe25d_k4_*.hip = the filter and update kernels, one
-// file per real type so that they compile in parallel): kernel arguments, index helpers, the small
+// file per real type -- K4: per real type and group height -- so that they compile in parallel): kernel arguments, index helpers, the small
 // arithmetic helpers that several kernels must round identically, and the kernel pickers' declarations.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -163,7 +163,11 @@ template <typename T> FilterKernel<T> spu_filter_kernel_for(const SuperPlan &P);
 template <typename T> FilterLoopKernel<T> spu_filter_loop_kernel_for(const SuperPlan &P);   // pe25d_k1.h (null: no looping form)
 template <typename T> FilterKernel<T> pgf_filter_kernel_for(const SuperPlan &P);            // pe25d_k3.h
 template <typename T> FilterKernel<T> pit2d_kernel_for(const SuperPlan &P);                 // pe25d_k3.h
-template <typename T> FilterKernel<T> update_rows_kernel_for(int rows_per_group, bool same);  // pe25d_k4.h (R = 3 or 7)
+template <typename T, int R> FilterKernel<T> update_rows_kernel_rt(bool same, bool oddtop);   // pe25d_k4.h, instantiated in pe25d_k4_f*_r*.hip
+// oddtop: the march starts on an odd level (whole columns, even L): anchors requested with the even levels only
+template <typename T> inline FilterKernel<T> update_rows_kernel_for(int rows_per_group, bool same, bool oddtop = false) {
+    return rows_per_group == 7 ? update_rows_kernel_rt<T, 7>(same, oddtop) : update_rows_kernel_rt<T, 3>(same, oddtop);
+}  // pe25d_k4.h (R = 3 or 7)
 constexpr int kUpdCols = 62;      // row-group update kernel: columns a wave produces (lanes 0 and 63 carry the halo columns)
 constexpr int kFftThreads = 256;  // generic filter path; the composite path sizes the workgroup from its plan
 

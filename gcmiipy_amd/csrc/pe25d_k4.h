@@ -36,7 +36,9 @@ template <int R> struct UpdTile {
     static constexpr int kSlots = kOwn + 5 * R;
 };
 // SAME: the stage state is the base state (predictor): no base-state requests
-template <typename T, int R, bool SAME>
+// ODDTOP: the march starts on an odd level (L even, whole columns): the geopotential anchor is then requested with the
+// even levels only -- an odd level takes its anchor from the tile of the level below and never reads its own
+template <typename T, int R, bool SAME, bool ODDTOP = false>
 __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T> a) {
     using TL = UpdTile<R>;
     extern __shared__ unsigned char upd_lds_raw[];
@@ -92,11 +94,12 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
         const long rn = ix.r3(jg - 1), rs = ix.r3(jend);
         const int ss = nact + 1;
         T h[2][10];
-        const auto load = [&](T (&d)[10], int k) {
+        const auto load = [&](T (&d)[10], int k, bool anch = true) {
             const long kl = (long)k * W;
             d[0] = a.su[rn + kl + i]; d[1] = a.sv[rn + kl + i]; d[2] = a.st[rn + kl + i]; d[3] = a.sq[rn + kl + i];
             d[4] = a.su[rs + kl + i]; d[5] = a.sv[rs + kl + i]; d[6] = a.st[rs + kl + i]; d[7] = a.sq[rs + kl + i];
-            d[8] = a.spu[rs + kl + i]; d[9] = a.phi[rs + (long)(k & ~1) * W + i];
+            d[8] = a.spu[rs + kl + i];
+            if (anch || !ODDTOP) d[9] = a.phi[rs + (long)(k & ~1) * W + i];
         };
         const auto put = [&](const T (&d)[10], int buf) {
             T *t = t0 + buf * kBuf;
@@ -106,21 +109,21 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
             for (int f = 0; f < 5; ++f) t[(TL::kMain + f * (R + 2) + ss) * 64] = d[4 + f];
             t[(TL::kPhi + nact) * 64] = d[9];
         };
-        load(h[0], k0);
+        load(h[0], k0, false);
         put(h[0], 0);
-        if (k0 - 1 >= kmin) { load(h[1], k0 - 1); put(h[1], 1); }
+        if (k0 - 1 >= kmin) { load(h[1], k0 - 1, true); put(h[1], 1); }
         // requests are unconditional (level clamped to kmin): a conditional one would make the compiler
         // size its in-order vmcnt waits for the path without it, i.e. wait for the newest requests too
-        load(h[0], max(k0 - 2, kmin));
+        load(h[0], max(k0 - 2, kmin), false);
         __syncthreads();
         for (int k = k0;;) {
-            load(h[1], max(k - 3, kmin));
+            load(h[1], max(k - 3, kmin), true);
             if (k - 2 >= kmin) put(h[0], bf);
             if (k == k_lo) break;
             __syncthreads();
             { const int t = bc; bc = bm; bm = bf; bf = t; }
             --k;
-            load(h[0], max(k - 3, kmin));
+            load(h[0], max(k - 3, kmin), false);
             if (k - 2 >= kmin) put(h[1], bf);
             if (k == k_lo) break;
             __syncthreads();
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
         asm volatile("" : "+s"(lo), "+s"(hi));
         return (__attribute__((address_space(1))) char *)(((unsigned long long)hi << 32) | lo);      // global, not flat
     };
-    const auto load = [&](T (&d)[11], int k) {
+    const auto load = [&](T (&d)[11], int k, bool anch = true) {
         // (the lane offset is made opaque once per level, so that its zero extension stays next to the
         // requests and they take the scalar-base + 32-bit-offset form)
         unsigned ol = ob;
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
         const long o = rc + (long)k * W;
         d[0] = at(a.su + o); d[1] = at(a.sv + o); d[2] = at(a.st + o); d[3] = at(a.sq + o);
         d[4] = at(a.spu + o); d[6] = at(a.pgfu + o);
-        d[5] = at(a.phi + (rc + (long)(k & ~1) * W));        // the anchor at or below k (odd k: unused, and a cache hit)
+        if (anch || !ODDTOP) d[5] = at(a.phi + (rc + (long)(k & ~1) * W));        // the anchor at or below k (odd k: unused, and a cache hit)
         if (!same) { d[7] = at(a.u + o); d[8] = at(a.v + o); d[9] = at(a.t + o); d[10] = at(a.q + o); }
     };
     const auto put = [&](const T (&d)[11], int buf) {
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
     T rc_c = T(0.0), rc_s = T(0.0);
     T fu_up = T(0.0), fv_up = T(0.0), ft_up = T(0.0), fq_up = T(0.0);
     T cs_u = T(0.0), cs_v = T(0.0);                              // sum_k dsig[k] u_n[k], v_n[k] (pe_pit2d_kernel)
-    load(q[0], k0);
+    load(q[0], k0, false);
     if (k_hi < L) {
         const T *part = a.part + (long)seg * a.part_stride;
         const T sgb_hi = lv_sigb[k_hi];
@@ -218,8 +221,8 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
         fq_up = face_flux_v(a.sq[rc + kp0 + i], q[0][3], sd_cp);
     }
     put(q[0], 0);
-    if (k0 - 1 >= kmin) { load(q[1], k0 - 1); put(q[1], 1); }
-    load(q[0], max(k0 - 2, kmin));                               // unconditional, clamped: see the loader wave
+    if (k0 - 1 >= kmin) { load(q[1], k0 - 1, true); put(q[1], 1); }
+    load(q[0], max(k0 - 2, kmin), false);                        // unconditional, clamped: see the loader wave
     // geopotential anchors (see phi_up): an odd level k steps up from the anchor phi[k-1] (tile of
     // level k-1) and leaves the level k-1 exner factors, anchors and south theta to the even level below
     bool have_lo = false;
@@ -350,14 +353,14 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
     // two request sets that swap BY NAME (loop unrolled by two): a register copy of a value still in
     // flight would make the wave wait for it at once
     for (int k = k0;;) {
-        load(q[1], max(k - 3, kmin));
+        load(q[1], max(k - 3, kmin), true);
         level(k);
         if (k - 2 >= kmin) put(q[0], bf);
         if (k == k_lo) break;
         __syncthreads();
         { const int t = bc; bc = bm; bm = bf; bf = t; }
         --k;
-        load(q[0], max(k - 3, kmin));
+        load(q[0], max(k - 3, kmin), false);
         level(k);
         if (k - 2 >= kmin) put(q[1], bf);
         if (k == k_lo) break;
@@ -371,10 +374,12 @@ __global__ __launch_bounds__(64 * (R + 1)) void pe_update_rows_kernel(PeArgsT<T>
     }
 }
 
-template <typename T>
-FilterKernel<T> update_rows_kernel_for(int rows_per_group, bool same) {
-    if (rows_per_group == 7) return same ? pe_update_rows_kernel<T, 7, true> : pe_update_rows_kernel<T, 7, false>;
-    return same ? pe_update_rows_kernel<T, 3, true> : pe_update_rows_kernel<T, 3, false>;
+// the four instantiations of one (real type, rows per workgroup): a translation unit each (pe25d_k4_f{64,32}_r{3,7}.hip),
+// so that they compile in parallel
+template <typename T, int R>
+FilterKernel<T> update_rows_kernel_rt(bool same, bool oddtop) {
+    if (oddtop) return same ? pe_update_rows_kernel<T, R, true, true> : pe_update_rows_kernel<T, R, false, true>;
+    return same ? pe_update_rows_kernel<T, R, true> : pe_update_rows_kernel<T, R, false>;
 }
 
 }  // namespace gcm
