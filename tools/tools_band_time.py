@@ -66,6 +66,12 @@ def main():
         if model != "PE25D":
             core.snapshot()
         eng = HipBandEngine(core, torch) if n > 1 else None
+        if "phys" in a.workload:
+            # BASELINE configs[4]: dynamics + solar_timestep every step (gcm_set_physics); on a band the ghost rows are
+            # radiated locally inside gcm_band_run
+            import numpy as np
+            core.set_ground(np.full((nrows, W), 288.0))
+            (eng if eng is not None else core).set_physics(geom, bench.PHYS_UTC0)
         # the exchange goes to the band itself (one-rank communicator / device-local copy): neighbours = rank 0
         runner = BandRunner(eng, rank, n, (tdist if tdist is not None else LoopbackDist()) if n > 1 else None,
                             north=0 if n > 1 else None, south=0 if n > 1 else None)
