@@ -329,7 +329,7 @@ def _worker(rank, world, port, model, outdir):
                    halo_steps=1 if model == "c3" else 2)
         c.set_state(**{k: v[row0:row0 + n] for k, v in f.items()})
     else:
-        H, W, L, steps, dt = 14, 20, 5, 2, 120.0
+        H, W, L, steps, dt = 14, 20, 5, 2 if model == "pe" else 3, 120.0
         geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
         ic = _ic_pe(geom)
         row0, n = split_rows(H, world)[rank]
@@ -337,18 +337,22 @@ def _worker(rank, world, port, model, outdir):
         c = g.Core(g._lib.PE25D, W, n, L, geom=geom, nranks=world, rank=rank, global_height=H, row0=row0,
                    stream=torch.cuda.current_stream().cuda_stream)
         c.set_state(ic[0][sl], *[a[:, sl] for a in ic[1:]])
-    runner = BandRunner(HipBandEngine(c, torch, stream_aware=False), rank, world, dist)
+    eng = HipBandEngine(c, torch, stream_aware=False)
+    if model == "pephys":             # BASELINE configs[4]'s second phase on bands that are separate processes
+        c.set_ground(_ic_gt(H, W)[sl])
+        eng.set_physics(geom, UTC0)
+    runner = BandRunner(eng, rank, world, dist)
     runner.run(1, dt)                 # chunked path: a partial window first, then the rest
     runner.run(steps - 1, dt)
     torch.cuda.synchronize()
-    st = c.get_state()
-    np.savez(os.path.join(outdir, "r%d.npz" % rank), **{k: a for k, a in zip("puvtq", st) if a is not None})
+    st = c.get_state() + ([c.get_ground()] if model == "pephys" else [])
+    np.savez(os.path.join(outdir, "r%d.npz" % rank), **{k: a for k, a in zip("puvtqg", st) if a is not None})
     c.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model,world", [("c3", 2), ("c3deep", 2), ("pe", 2), ("c3deep", 4), ("pe", 4)])
+@pytest.mark.parametrize("model,world", [("c3", 2), ("c3deep", 2), ("pe", 2), ("c3deep", 4), ("pe", 4), ("pephys", 2), ("pephys", 3)])
 def test_band_runner_processes_one_gpu(tmp_path, model, world):
     """world = 4: every rank has two distinct ring neighbours (the N = 2 ring talks to one peer
     twice); four processes share the GPU (the box allows six)"""
@@ -367,11 +371,14 @@ def test_band_runner_processes_one_gpu(tmp_path, model, world):
         geom = geometry.gen_geometry(H, W, L, sig_func=geometry.manabe_sig)
         ref = g.Core(g._lib.PE25D, W, H, L, geom=geom)
         ref.set_state(*_ic_pe(geom))
-        ref.step(2, 120.0)
-    want = ref.get_state()
+        if model == "pephys":
+            ref.set_ground(_ic_gt(H, W))
+            ref.set_physics(geom, UTC0)
+        ref.step(2 if model == "pe" else 3, 120.0)
+    want = ref.get_state() + ([ref.get_ground()] if model == "pephys" else [])
     ref.close()
-    for f, k in enumerate("puvtq"):
-        axis = 1 if (model == "pe" and f > 0) else 0
+    for f, k in enumerate("puvtqg"[:len(want)]):
+        axis = 1 if (model in ("pe", "pephys") and 0 < f < 5) else 0
         got = np.concatenate([p_[k] for p_ in parts], axis=axis)
         assert rel_err(got, want[f]) < 1e-13, (k, rel_err(got, want[f]))
 

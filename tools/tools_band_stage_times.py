@@ -19,7 +19,7 @@ for a, b in zip(k4[:-1], k4[1:]):
     k3 = [e for e in inside if "pe_pgf_filter" in e[0]]
     if len(k2a) != 1 or len(k3) != 1:
         continue
-    kind = "true" if ", true>" in b[0] or "true>" in b[0].split("pe_update_rows_kernel")[1][:20] else "false"
+    kind = b[0].split("pe_update_rows_kernel<")[1].split(">")[0].split(",")[2].strip()      # <T, R, SAME, ...>: SAME = predictor
     stages[kind].append((k2a[0][1] - a[2], k2a[0][2] - k2a[0][1], k3[0][1] - k2a[0][2], k3[0][2] - k3[0][1], b[1] - k3[0][2], b[2] - b[1], b[2] - a[2]))
 names = ("K4end->K2a", "K2a", "K2a->K3", "K3", "K3end->K4", "K4 interior", "stage")
 tot = 0.0
