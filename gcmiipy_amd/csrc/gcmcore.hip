@@ -622,6 +622,9 @@ static int halo_run(gcm_handle *h, bool pack, void *north, void *south, void *st
         h->since_exchange = 0;
         if (south) h->ghosts_current = true;       // (the total variation reads the south ghost row only)
     }
+    // GCM_PE25D: ghost rows filled on any stream but the library's second one (a host-driven exchange, gcm_band_run's
+    // first exchange of a run): the next stage's second-stream work must follow THAT, not only the last update kernel
+    if (!pack && h->pe && (hipStream_t)stream != pe25d_aux_stream(h->pe)) pe25d_fork_invalidate(h->pe);
     launch_seg_copy(c, (hipStream_t)stream);
     return launch_status(h);
 }

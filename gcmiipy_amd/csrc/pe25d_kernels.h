@@ -28,6 +28,7 @@ int pe25d_wait_edges(Pe25d *m, hipStream_t s, std::string *err);
 int pe25d_prep_ghost_rows(Pe25d *m, std::string *err);   // gcm_band_run: behind the unpack on the second stream
 hipStream_t pe25d_aux_stream(const Pe25d *m);
 void pe25d_join_third_stream(Pe25d *m, hipStream_t s);
+void pe25d_fork_invalidate(Pe25d *m);
 // a new non-blocking stream that demonstrably runs beside `main` (and `other`, may be null)
 hipStream_t concurrent_stream(hipStream_t main, hipStream_t other);
 void launch_spin(hipStream_t s, double us);   // GCM_BAND_EXCHANGE_DELAY_US: the loopback exchange takes that long

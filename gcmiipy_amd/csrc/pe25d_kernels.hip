@@ -751,6 +751,9 @@ void pe25d_join_third_stream(Pe25d *m, hipStream_t s) {
     (void)hipEventRecord(m->ev_cs, m->aux2);
     (void)hipStreamWaitEvent(s, m->ev_cs, 0);
 }
+// something chain B reads was queued on the caller's stream by somebody else (ghost rows unpacked there, the ground
+// temperature uploaded): the next stage's chain B follows that stream's position, not just the last K4
+void pe25d_fork_invalidate(Pe25d *m) { m->k4_fork_valid = false; }
 int pe25d_new_state_set(const Pe25d *m) { return (m->pack_set >= 0 && m->pack_set != 2) ? m->pack_set : m->cur_i; }
 
 Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string *err) {
@@ -1233,17 +1236,18 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         // two launches share the chip.
         const bool as = async_edges(m);
         hipStream_t se = as && m->aux ? m->aux : s;
-        if (as && m->aux) (void)hipStreamWaitEvent(m->aux, m->ev_join, 0);
         if (split_k1) (void)hipStreamWaitEvent(se, m->ev_a, 0);      // the edge rows' partial sums and K4 take spu of own rows
         if (split && p2 && m->nseg_edge > 1) {
             // a band's edge rows are marched in level segments (below): the partial sums of conv they start from,
-            // behind K1 on chain B (beside the interior rows' K4 this kernel took 50 us instead of 14)
+            // behind K1 on chain B and ahead of its wait for K3 (beside the interior rows' K4 this kernel took 50 us
+            // instead of 14)
             PeArgsT<T> c = a;
             c.nseg = m->nseg_edge;
             c.j0 = j0; c.j1 = j0 + kGhost + 1;            // (K4 of row j also takes the sums of row j + 1)
             c.jb0 = j1 - kGhost; c.jb1 = j1 + 1;
             hipLaunchKernelGGL(pe_part_kernel<T>, dim3((unsigned)((W + 255) / 256) * (2 * kGhost + 2)), dim3(256), 0, se, c);
         }
+        if (as && m->aux) (void)hipStreamWaitEvent(m->aux, m->ev_join, 0);      // the edge rows' K4 takes pgfu
         if (split && p2 && m->nseg_edge > 1) {
             // the edge rows in level segments: a quarter of the chain of dependent levels, so the pack
             // and the exchange start while the interior rows are still at work
@@ -1645,7 +1649,10 @@ int pe25d_ground(Pe25d *m, bool set, const double *in, double *out, hipStream_t 
                        : hipMemcpyAsync(out, m->gt, bytes, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { *err = "hip: ground temperature transfer failed"; return GCM_ERR_HIP; }
-    if (set) m->gt_set = true;
+    if (set) {
+        m->gt_set = true;
+        m->k4_fork_valid = false;
+    }
     return GCM_OK;
 }
 
