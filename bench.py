@@ -264,22 +264,26 @@ def run_workload(cx, name, steps, warmup, variant="fused", world=None, want_kern
             since[0] = 0
     # Deep-halo bands whose exchange the library posts itself: the exchange can be hidden behind the
     # interior rows of the steps around it at the price of four more launches per window
-    # (gcm_set_band_overlap).  Whether that pays depends on what the exchange costs between THESE
-    # devices, so both sequences are timed here (max over ranks) and the faster one is kept.
+    # (gcm_set_band_overlap).  GCM_PE25D bands: the interior rows' update can be held back until the edge rows'
+    # update has been dispatched, which gets the edge rows -- and the exchange -- out 45 us earlier per stage and
+    # costs the interior rows ~10 us (profiles/r04/band_matrix_edges_first.txt: it pays from ~30 us per exchange).
+    # Whether either pays depends on what the exchange costs between THESE devices, so both sequences are
+    # timed here (max over ranks) and the faster one is kept.
     overlap_probe = None
-    if active and world > 1 and not solo and k > 1 and model != "PE25D" and getattr(runner, "native", False):
+    if active and world > 1 and not solo and (k > 1 or model == "PE25D") and getattr(runner, "native", False):
         overlap_probe = {}
+        npr = 6 * k if model != "PE25D" else 24
         for flag in (0, 1):
             core.set_band_overlap(flag)
             run(2 * k)
             fence()
             t0 = time.perf_counter()
-            run(6 * k)
+            run(npr)
             fence()
             tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
                               device="cuda" if cx.backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            overlap_probe["overlap" if flag else "plain"] = float(tt.item()) / (6 * k) * 1e3
+            overlap_probe["overlap" if flag else "plain"] = float(tt.item()) / npr * 1e3
         overlap_probe["chosen"] = "overlap" if overlap_probe["overlap"] < overlap_probe["plain"] else "plain"
         core.set_band_overlap(overlap_probe["chosen"] == "overlap")
         if life is not None and since[0]:

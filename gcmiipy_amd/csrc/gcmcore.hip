@@ -721,6 +721,7 @@ int gcm_set_exchange(gcm_handle *h, const gcm_exchange *x) {
     h->xch_set = true;
     h->primed = false;
     if (const char *e = getenv("GCM_BAND_OVERLAP")) h->band_overlap = e[0] == '1';
+    if (h->pe) pe25d_set_edges_first(h->pe, h->band_overlap);
     {
         const char *e = getenv("GCM_BAND_COMM_STREAM");     // diagnostic: the exchange on the comm stream, a join per stage (round 1)
         h->on_comm = e && e[0] == '1';
@@ -838,6 +839,7 @@ int gcm_set_band_overlap(gcm_handle *h, int on) {
     if (!h) return GCM_ERR_ARG;
     if (h->wrap) return fail(h, GCM_ERR_STATE, "gcm_set_band_overlap: handle is not a latitude band");
     h->band_overlap = on != 0;
+    if (h->pe) pe25d_set_edges_first(h->pe, h->band_overlap);
     return GCM_OK;
 }
 

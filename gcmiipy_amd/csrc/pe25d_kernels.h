@@ -29,6 +29,7 @@ int pe25d_prep_ghost_rows(Pe25d *m, std::string *err);   // gcm_band_run: behind
 hipStream_t pe25d_aux_stream(const Pe25d *m);
 void pe25d_join_third_stream(Pe25d *m, hipStream_t s);
 void pe25d_fork_invalidate(Pe25d *m);
+void pe25d_set_edges_first(Pe25d *m, bool on);   // gcm_set_band_overlap on a GCM_PE25D band
 // a new non-blocking stream that demonstrably runs beside `main` (and `other`, may be null)
 hipStream_t concurrent_stream(hipStream_t main, hipStream_t other);
 void launch_spin(hipStream_t s, double us);   // GCM_BAND_EXCHANGE_DELAY_US: the loopback exchange takes that long

@@ -530,6 +530,15 @@ struct Pe25d {
     hipEvent_t ev_a = nullptr, ev_edges = nullptr;
     bool edges_pending = false;
     bool edges_ev_valid = false;                // ev_edges has been recorded at least once (a wait for it means something)
+    // gcm_set_band_overlap(1) on a GCM_PE25D band: the interior rows' K4 is held back until chain B has reached the
+    // edge rows' K4 (an event recorded right in front of it), so that the edge rows' workgroups are dispatched
+    // first: they then take 15-20 us instead of the 60-70 they take when both launches race for the chip, and the
+    // pack and the exchange start that much earlier -- at the price of the ~8 us per stage the interior rows wait.
+    // Worth it where an exchange takes longer than the ~20 us of slack the edge chain has otherwise; bench.py --gpus N
+    // times both on the real ring and keeps the faster.
+    bool edges_first = false;
+    hipEvent_t ev_pre_edge = nullptr;
+    bool pre_edge_pending = false;
 };
 
 template <typename T> static PeBufs<T> &bufs(Pe25d *m);
@@ -754,6 +763,7 @@ void pe25d_join_third_stream(Pe25d *m, hipStream_t s) {
 // something chain B reads was queued on the caller's stream by somebody else (ghost rows unpacked there, the ground
 // temperature uploaded): the next stage's chain B follows that stream's position, not just the last K4
 void pe25d_fork_invalidate(Pe25d *m) { m->k4_fork_valid = false; }
+void pe25d_set_edges_first(Pe25d *m, bool on) { m->edges_first = on; }
 int pe25d_new_state_set(const Pe25d *m) { return (m->pack_set >= 0 && m->pack_set != 2) ? m->pack_set : m->cur_i; }
 
 Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string *err) {
@@ -865,7 +875,8 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
         }
     }
     if (const char *e = getenv("GCM_PE_STOP_EVENTS")) m->stop_events = atoi(e) != 0;
-    if (hipEventCreateWithFlags(&m->ev_k4, hipEventDisableTiming) != hipSuccess ||
+    if (hipEventCreateWithFlags(&m->ev_pre_edge, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->ev_k4, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_cs, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming) != hipSuccess ||
@@ -883,6 +894,7 @@ void pe25d_destroy(Pe25d *m) {
     if (m->ev_edges) (void)hipEventDestroy(m->ev_edges);
     if (m->ev_cs) (void)hipEventDestroy(m->ev_cs);
     if (m->ev_k4) (void)hipEventDestroy(m->ev_k4);
+    if (m->ev_pre_edge) (void)hipEventDestroy(m->ev_pre_edge);
     if (m->aux2) {
         (void)hipStreamSynchronize(m->aux2);
         (void)hipStreamDestroy(m->aux2);
@@ -1248,6 +1260,10 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
             hipLaunchKernelGGL(pe_part_kernel<T>, dim3((unsigned)((W + 255) / 256) * (2 * kGhost + 2)), dim3(256), 0, se, c);
         }
         if (as && m->aux) (void)hipStreamWaitEvent(m->aux, m->ev_join, 0);      // the edge rows' K4 takes pgfu
+        if (as && m->aux && m->edges_first && split) {
+            (void)hipEventRecord(m->ev_pre_edge, se);          // chain B is about to launch the edge rows' K4
+            m->pre_edge_pending = true;
+        }
         if (split && p2 && m->nseg_edge > 1) {
             // the edge rows in level segments: a quarter of the chain of dependent levels, so the pack
             // and the exchange start while the interior rows are still at work
@@ -1292,6 +1308,8 @@ static void half_t(Pe25d *m, int stage_set, int out_set, double dt, int j0, int 
         }
     } else {
         if (split) {
+            if (m->pre_edge_pending) (void)hipStreamWaitEvent(s, m->ev_pre_edge, 0);
+            m->pre_edge_pending = false;
             update_rows(j0 + kGhost, j1 - kGhost, 0, 0, s, m->ev_k4);
             m->k4_fork_valid = m->stop_events;
         }

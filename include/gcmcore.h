@@ -304,6 +304,11 @@ int gcm_band_run(gcm_handle *h, int nsteps, double dt);
  * data).  Same kernels on the same rows: bit-identical results.  Costs four more launches per window,
  * so it pays where the exchange takes longer than that (measured per run by bench.py --gpus N, which
  * times both and keeps the faster).  Default off, or GCM_BAND_OVERLAP=1 at gcm_set_exchange.       */
+/* GCM_PE25D bands: on = 1 holds the interior rows' update kernel back until the library's second stream has reached
+ * the edge rows' update kernel, so that the edge rows' workgroups are dispatched first (15-20 us instead of the 60-70
+ * they take when the two launches race for the chip): the pack and the exchange of a stage start ~45 us earlier, the
+ * interior rows ~10 us later.  Same kernels on the same rows: bit-identical results.  Pays where an exchange takes
+ * longer than ~30 us (measured per run by bench.py --gpus N, as above).  Default off.                              */
 int gcm_set_band_overlap(gcm_handle *h, int on);
 
 int gcm_sync(gcm_handle *h);

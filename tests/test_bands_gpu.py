@@ -435,6 +435,7 @@ def _rccl_self_worker(rank, port, model, outdir):
         from gcmiipy_amd.rccl import RcclP2P
         ring = RcclP2P(None, 0, 1, uid_bytes=RcclP2P.new_unique_id())   # bench.py's bring-up path
         ring.self_check()
+        assert ring.count() == 1                   # ncclCommCount: what bench.py prints as rccl_ranks
     else:
         ring = dist
     phys = model == "pephys"
@@ -642,9 +643,10 @@ def test_band_run_chains_at_overlapping_size(dtype, phys, monkeypatch):
     other band tests a kernel is over before the other chain starts, so a missing dependency could not show.  Here
     the band is 48 rows x 1440 columns x 24 levels (edge rows marched in level segments, kernels of tens of
     microseconds on either stream), five steps inside gcm_band_run calls, fp64 and fp32, with the loopback exchange
-    (the band is its own neighbour = the periodic single domain).  Three orchestrations -- the two chains, one
+    (the band is its own neighbour = the periodic single domain).  Four orchestrations -- the chains of the product, one
     stream only (GCM_PE_SINGLE_STREAM=1), the exchange on the comm stream with a join per stage
-    (GCM_BAND_COMM_STREAM=1) -- must all give the single domain's bits; a solar_timestep and a gcm_set_state between
+    (GCM_BAND_COMM_STREAM=1), the edge rows' update dispatched ahead of the interior rows' (GCM_BAND_OVERLAP=1) --
+    must all give the single domain's bits; a solar_timestep and a gcm_set_state between
     runs exercise the reset of the queued ghost-row work (ghost_ready)."""
     import torch
     import gcmiipy_amd as g
@@ -675,8 +677,9 @@ def test_band_run_chains_at_overlapping_size(dtype, phys, monkeypatch):
         ref.set_physics(geom, UTC0)
     want = drive(ref, lambda n: ref.step(n, dt))
     ref.close()
-    for env in ({}, {"GCM_PE_SINGLE_STREAM": "1"}, {"GCM_BAND_COMM_STREAM": "1"}):
-        for k in ("GCM_PE_SINGLE_STREAM", "GCM_BAND_COMM_STREAM"):
+    # (GCM_BAND_OVERLAP=1 = gcm_set_band_overlap(1): the interior rows' update held back until the edge rows' is dispatched)
+    for env in ({}, {"GCM_PE_SINGLE_STREAM": "1"}, {"GCM_BAND_COMM_STREAM": "1"}, {"GCM_BAND_OVERLAP": "1"}):
+        for k in ("GCM_PE_SINGLE_STREAM", "GCM_BAND_COMM_STREAM", "GCM_BAND_OVERLAP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

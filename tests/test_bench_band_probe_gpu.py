@@ -70,7 +70,8 @@ def test_run_workload_pe25d_band_path(monkeypatch):
     with torch.cuda.stream(torch.cuda.Stream()):
         res = bench.run_workload(cx, "c4", 4, 2, want_kernel=False)
     assert res["n_gpus"] == 8 and res["ms_per_step"] > 0 and np.isfinite(res["value"])
-    assert res["band_overlap_probe_ms_per_step"] is None
+    probe = res["band_overlap_probe_ms_per_step"]           # GCM_PE25D: the edge rows' update dispatched first, or not
+    assert probe["chosen"] in ("plain", "overlap") and probe["plain"] > 0 and probe["overlap"] > 0
 
 
 def test_bench_starts_its_own_ranks(tmp_path):
