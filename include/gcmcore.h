@@ -245,7 +245,9 @@ int gcm_restore(gcm_handle *h);
  * needs into / unpacks them from caller-owned DEVICE buffers (e.g. torch tensors
  * handed to torch.distributed / RCCL send-recv); it never calls a collective
  * itself.  `side` 0 = towards row 0 (north), 1 = towards the last row (south).
- * gcm_halo_bytes gives the buffer size for one side.                           */
+ * gcm_halo_bytes gives the buffer size for one side (GCM_PE25D: the two rows of p and of
+ * u, v, t, q on every level in the handle's storage type, then the two rows of the ground
+ * temperature in float64 -- see gcm_set_physics).                                            */
 size_t gcm_halo_bytes(const gcm_handle *h);
 int gcm_halo_pack(gcm_handle *h, int side, void *dev_buf, void *stream);
 int gcm_halo_unpack(gcm_handle *h, int side, const void *dev_buf, void *stream);
