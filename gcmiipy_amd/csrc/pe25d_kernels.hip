@@ -30,21 +30,22 @@ namespace gcm {
 // The per-level stp that phi needs after the column sum is parked in LDS, park[k][thread],
 // instead of a round trip through HBM.
 constexpr int kColThreads = 128;
+// sum_k dsig[k] u[k] and sum_k dsig[k] v[k] of one column, k = L-1 .. 0 with cs_acc, as K4 accumulates them.  Eight levels of
+// BOTH fields are requested at a time, then added in order: one memory latency per eight levels (a load per iteration
+// waits one per level: 20 us for the two ghost rows of a band, on the edge rows' chain; round 4: the two fields together)
 template <typename T>
-__device__ __forceinline__ T column_sum(const T *col, const T *dsig, int L, int W) {
-    // eight levels requested at a time, then added in order (a load per iteration waits a memory
-    // latency per level: 20 us for the two ghost rows of a band, on the stage's critical path)
-    T acc = T(0.0);
+__device__ __forceinline__ void column_sum2(const T *cu, const T *cv, const T *dsig, int L, int W, T *su, T *sv) {
+    T au = T(0.0), av = T(0.0);
     int k = L - 1;
     for (; k >= 7; k -= 8) {
-        T x[8];
+        T x[8], y[8];
 #pragma unroll
-        for (int n = 0; n < 8; ++n) x[n] = col[(long)(k - n) * W];
+        for (int n = 0; n < 8; ++n) { x[n] = cu[(long)(k - n) * W]; y[n] = cv[(long)(k - n) * W]; }
 #pragma unroll
-        for (int n = 0; n < 8; ++n) acc = cs_acc(acc, x[n], dsig[k - n]);
+        for (int n = 0; n < 8; ++n) { au = cs_acc(au, x[n], dsig[k - n]); av = cs_acc(av, y[n], dsig[k - n]); }
     }
-    for (; k >= 0; --k) acc = cs_acc(acc, col[(long)k * W], dsig[k]);
-    return acc;
+    for (; k >= 0; --k) { au = cs_acc(au, cu[(long)k * W], dsig[k]); av = cs_acc(av, cv[(long)k * W], dsig[k]); }
+    *su = au; *sv = av;
 }
 // LMAX > 0: L <= LMAX and the per-level stp stay in registers (loops unrolled over LMAX; no LDS
 // park, so the occupancy is not limited by it); LMAX == 0: any L, stp parked in LDS
@@ -75,8 +76,10 @@ __global__ __launch_bounds__(kColThreads) void pe_geopot_kernel(PeArgsT<T> a) {
     if (i >= W) return;
     if (CS) {
         // a band's ghost rows in one launch: their column sums too (see pe_colsum_kernel)
-        a.scs_u[ix.r2(j) + i] = column_sum(a.su + ix.r3(j) + i, a.dsig, L, W);
-        a.scs_v[ix.r2(j) + i] = column_sum(a.sv + ix.r3(j) + i, a.dsig, L, W);
+        T cs_u, cs_v;
+        column_sum2(a.su + ix.r3(j) + i, a.sv + ix.r3(j) + i, a.dsig, L, W, &cs_u, &cs_v);
+        a.scs_u[ix.r2(j) + i] = cs_u;
+        a.scs_v[ix.r2(j) + i] = cs_v;
     }
     if (j < a.geo_j0 || j >= a.geo_j1) return;
     T *pk = park + threadIdx.x;
@@ -236,8 +239,10 @@ __global__ __launch_bounds__(256) void pe_colsum_kernel(PeArgsT<T> a) {
     const int na = a.j1 - a.j0;
     if (i >= W || jrel >= na + (a.jb1 - a.jb0)) return;
     const int j = jrel < na ? a.j0 + jrel : a.jb0 + (jrel - na);
-    a.scs_u[ix.r2(j) + i] = column_sum(a.su + ix.r3(j) + i, a.dsig, a.L, W);
-    a.scs_v[ix.r2(j) + i] = column_sum(a.sv + ix.r3(j) + i, a.dsig, a.L, W);
+    T cs_u, cs_v;
+    column_sum2(a.su + ix.r3(j) + i, a.sv + ix.r3(j) + i, a.dsig, a.L, W, &cs_u, &cs_v);
+    a.scs_u[ix.r2(j) + i] = cs_u;
+    a.scs_v[ix.r2(j) + i] = cs_v;
 }
 
 using PeArgs = PeArgsT<double>;   // the diagnostics and the column physics below are fp64 only
