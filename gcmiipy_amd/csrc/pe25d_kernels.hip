@@ -839,8 +839,10 @@ Pe25d *pe25d_create(const gcm_config &cfg, hipStream_t main_stream, std::string 
         // fp32: 153 VGPRs and 34 KB of tiles per 3-row workgroup let THREE of them share a CU (three waves per SIMD; the
         // 7-row form holds one 8-wave workgroup, two waves per SIMD): c4_f32 1.214 -> 1.126 ms per step (round 4, A/B
         // on one box; 5-row groups, 6 waves, place only one workgroup per CU and take 1.44).  fp64 (215 / 231 VGPRs)
-        // stays at two waves per SIMD either way: 3-row groups only where the band is short.
-        m->upd_rows = (m->H <= 256 || m->f32) ? 3 : 7;
+        // stays at two waves per SIMD either way: 3-row groups only where the band is short -- up to 360 rows they win
+        // (round 4, one box: a 360-row band of C4 1.050 -> 1.008 ms, of the 2880x1440x40 grid 3.461 -> 3.396), at 720
+        // rows the 7-row form does (C4 1.874 vs 1.907, the 2880-column grid 6.597 vs 6.627).
+        m->upd_rows = (m->H <= 400 || m->f32) ? 3 : 7;
         bool forced = false;
         if (const char *e = getenv("GCM_PE_LEVEL_SEGMENTS")) { want = atoi(e); forced = true; }
         if (const char *e = getenv("GCM_PE_PIT2D")) m->pit2d = atoi(e) != 0;      // 0: pit from the 3-D fields (pe_pit_kernel)
