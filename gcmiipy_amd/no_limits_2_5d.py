@@ -59,9 +59,12 @@ def full_timestep(p, u, v, t, q, g, dt, utc, geom, stats=STATS):
     return (*_wrap_out(c.get_state(), units), g)
 
 
-def run_model(height, width, layers, dt, timesteps, callback, stats=STATS, bump=None):
+def run_model(height, width, layers, dt, timesteps, callback, stats=STATS, bump=None, physics=False):
     """no_limits_2_5d.py:220-236 (and test_geography.py:6-23 with `bump=(j, i, metres)`): the
-    state stays in HBM for all `timesteps`; STATS come from device reductions every step."""
+    state stays in HBM for all `timesteps`; STATS come from device reductions every step.
+    physics=True: every step is followed by solar_timestep(t, p, g, dt, utc, geom) with utc = 0, dt, 2 dt, ...
+    -- the lines the reference keeps below full_timestep's early return (:93-96) and run_model's clock (:222, :231);
+    on the device both phases are one gcm_step (gcm_set_physics), and the returned g carries the new ground temperature."""
     geom = geometry.gen_geometry(height, width, layers, sig_func=geometry.manabe_sig)
     if bump is not None:
         geom.heightmap[bump[0], bump[1]] = bump[2]
@@ -71,12 +74,17 @@ def run_model(height, width, layers, dt, timesteps, callback, stats=STATS, bump=
     c = Core(_lib.PE25D, width, height, layers, geom=geom)
     try:
         c.set_state(p, u, v, t, q)
+        if physics:
+            c.set_ground(g.gt)
+            c.set_physics(geom, 0.0)
         for _ in range(timesteps):
             c.step(1, scalar(dt))
             _record(c, geom, stats)
             if callback:
                 callback(*c.get_state())
         p, u, v, t, q = c.get_state()
+        if physics:
+            g = GroundVars(c.get_ground(), g.gw, g.snow, g.ice)
     finally:
         c.close()
     return p, u, v, t, q, g, geom

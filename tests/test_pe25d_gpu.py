@@ -604,3 +604,28 @@ def test_set_physics_is_the_explicit_loop(g):
     with pytest.raises(GcmError, match="GCM_PE25D only"):
         sw.set_physics(geometry.gen_geometry(16, 32, 2, sig_func=geometry.manabe_sig), 0.0)
     sw.close()
+
+
+def test_run_model_with_physics_vs_oracle(g):
+    """the whole loop of BASELINE configs[4] as a user would run it -- gen_initial_conditions, then per step
+    matsuno_timestep + solar_timestep at utc = 0, dt, 2 dt ... -- through the drop-in run_model(physics=True) (one
+    gcm_step per step on the device) against the oracle's functions called in the reference's order"""
+    from gcmiipy_amd import no_limits_2_5d as m
+    from oracle import driver, dynamics as odyn, physics, geometry as ogeo
+    H, W, L, dt, steps = 16, 16, 5, 900.0, 4          # (square: the STATS record broadcasts geom.area (H,) against W)
+    stats = {k: [] for k in ("u_max", "u_min", "v_max", "v_min", "ke")}
+    got = m.run_model(H, W, L, dt, steps, None, stats=stats, physics=True)
+    og = ogeo.gen_geometry(H, W, L, sig_func=ogeo.manabe_sig)
+    p, u, v, t, q, gt = driver.gen_initial_conditions(og)
+    gt = np.asarray(getattr(gt, "gt", gt), dtype=np.float64)
+    v[0, 0, 0] = 0.1
+    u *= 0
+    st, utc = (p, u, v, t, q), 0.0
+    for _ in range(steps):
+        st = list(odyn.matsuno_timestep(*st, dt, og))
+        st[3], gt = physics.solar_timestep(st[3], st[0], gt, dt, utc, og)
+        utc += dt
+    for k, x, y in zip("puvtq", got[:5], st):
+        assert rel_err(x, y) < 1e-10, (k, rel_err(x, y))
+    assert rel_err(got[5].gt, gt) < 1e-10
+    assert not np.array_equal(got[5].gt, np.full((H, W), 360.0))          # the ground did cool / warm
