@@ -120,3 +120,29 @@ def test_unit_stripping_roundtrip():
     assert scalar(FakeQ(2.0, 60.0)) == 120.0
     assert strip(np.ones(2))[1] is None
     assert attach(np.ones(2), None).shape == (2,)
+
+
+def test_physics_and_exchange_struct_layouts_match_header():
+    """the ctypes mirrors of gcm_physics and gcm_exchange follow the header field for field"""
+    from gcmiipy_amd import _lib
+    src = open(os.path.join(ROOT, "include", "gcmcore.h")).read()
+
+    def fields_of(name):
+        end = src.index("} %s;" % name)
+        body = src[src.rindex("typedef struct {", 0, end):end]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.replace("typedef struct {", "").strip()
+            if not decl:
+                continue
+            names = decl.split(",")
+            first = names[0].split()[-1].lstrip("*")
+            out.append(first)
+            out += [n.strip().lstrip("*") for n in names[1:]]
+        return out
+
+    assert fields_of("gcm_physics") == [f[0] for f in _lib.Physics._fields_]
+    assert ctypes.sizeof(_lib.Physics) == 4 * 8 + 2 * 8
+    assert fields_of("gcm_exchange") == [f[0] for f in _lib.Exchange._fields_]
+    assert ctypes.sizeof(_lib.Exchange) == 8 + 2 * 4 + 4 * 8 + 4 * 8
